@@ -1,0 +1,137 @@
+/*
+ * mc_kernels.h - C ABI of libmotionclone_hip.so (gfx950 / MI355X).
+ *
+ * The reference (LPengYang/MotionClone @ 2024-10-16) has no native layer: its hot
+ * path reaches the GPU only through PyTorch / xformers operators.  This header is
+ * the boundary a maintainer binds instead (ctypes stub: INTEGRATION.md); each entry
+ * point names the reference operator(s) it replaces (paths relative to the
+ * reference repository root).
+ *
+ * Conventions:
+ *   - all activations fp16, channels-last token matrices [tokens, C] with an explicit
+ *     row stride (ld*, in elements); token order is (batch, frame, y, x);
+ *   - small parameter vectors (bias, gamma, beta, PE table) fp32;
+ *   - the caller owns every buffer including workspaces; the library allocates
+ *     nothing, never synchronises, launches only on `stream` (a hipStream_t), keeps
+ *     no mutable global state, and is graph-capturable;
+ *   - return value: 0 = MC_OK, -1 = bad shape/stride/alignment, -2 = unsupported
+ *     size, -3 = launch failure.  Pointers must be 16-byte aligned.
+ */
+#ifndef MC_KERNELS_H
+#define MC_KERNELS_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MC_ABI_VERSION 1
+int mc_version(void);
+
+/* ---- MFMA GEMM / implicit convolution ------------------------------------------------------
+ * C[M,N] = alpha * A[M,K] . W[N,K]^T + bias[m / rows_per_batch][n] + R[m][n]
+ * mode 0 DENSE    : nn.Linear / 1x1 conv  (attention.py:65,93,355-357,364; motion_module.py:113,135;
+ *                   resnet.py:181; diffusers FeedForward) and their data-gradients (W pre-transposed)
+ * mode 1 CONV_S1  : 3x3 stride 1 pad 1     (resnet.py:148,168; unet.py:98,249) and its data-gradient
+ * mode 2 CONV_S2  : 3x3 stride 2 pad 1     (resnet.py:94)
+ * mode 3 CONV_UP  : F.interpolate(nearest, 2x) + 3x3 (resnet.py:65,78), upsample never materialised
+ * mode 4 TCONV_S2 : data-gradient of mode 2
+ * A2 (optional) supplies channels [c1, ctot) - the skip concat of unet_blocks.py:634,740.
+ * K = ctot (dense) or 9*ctot (conv; k = tap*ctot + c).  K, ctot, c1 multiples of 64; N, ldc multiples of 4.
+ * tile: 0 = auto, 64 or 128 = block tile edge. */
+int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
+                int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
+                int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int tile, void* stream);
+
+/* ---- GroupNorm(32) [+SiLU] ------------------------------------------------------------------
+ * resnet.py:21-29,186-187,197-203; attention.py:61,105; motion_module.py:112,145; unet.py:245.
+ * Two-source input (a: channels [0,c1), b: [c1,ctot)).  partial: float[frames*mc_gn_nchunk(hw)*64]
+ * workspace; stats: float[frames*32*2] = (mean, rstd). */
+int mc_gn_nchunk(int hw);
+int mc_groupnorm_stats_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
+                           float eps, float* partial, float* stats, void* stream);
+int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
+                           const float* stats, const float* gamma, const float* beta, void* out, int ldo,
+                           int silu, void* stream);
+/* data-gradient (autograd of the above; reference motionclone_functions.py:236). bstats: float[frames*64] */
+int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
+                         const void* dz, int lddz, const float* stats, const float* gamma, const float* beta,
+                         int silu, float* partial, float* bstats, void* dx, int lddx, int accumulate,
+                         void* stream);
+
+/* ---- LayerNorm ------------------------------------------------------------------------------
+ * attention.py:189,206,212; motion_module.py:204,210.  pe (optional, float[nframes_pe][C]) is the
+ * sinusoidal temporal table of motion_module.py:237-246, added to row m at frame (m / hw) % nframes_pe
+ * (motion_module.py:279-282).  stats: float[M*2] = (mean, rstd), may be NULL. */
+int mc_layernorm_fwd_f16(const void* x, int ldx, void* y, int ldy, const float* gamma, const float* beta,
+                         const float* pe, int hw, int nframes_pe, float* stats, int M, int C, float eps,
+                         void* stream);
+int mc_layernorm_bwd_f16(const void* dy, int lddy, const void* x, int ldx, const float* stats,
+                         const float* gamma, const void* add, int ldadd, void* dx, int lddx, int M, int C,
+                         void* stream);
+
+/* ---- spatial self / text cross attention (flash-style) --------------------------------------
+ * attention.py:387-490 and the xformers slot :535-542.  Row of (batch b, i): q: b*Nq+i, k/v:
+ * (b / kv_bdiv)*Nk + j; head h occupies columns [h*d, (h+1)*d).  lse: float[nbatch*heads*Nq]. */
+int mc_attn_fwd_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o, int ldo,
+                    float* lse, int Nq, int Nk, int heads, int d, int nbatch, int kv_bdiv, float scale,
+                    void* stream);
+/* dq always; dk/dv when non-NULL (requires kv_bdiv == 1).  Dbuf: float[nbatch*heads*Nq] workspace. */
+int mc_attn_bwd_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const void* o,
+                    int ldo, const void* dO, int lddo, const float* lse, float* Dbuf, void* dq, int lddq,
+                    void* dk, int lddk, void* dv, int lddv, int Nq, int Nk, int heads, int d, int nbatch,
+                    int kv_bdiv, float scale, void* stream);
+
+/* ---- temporal attention + MotionClone guidance ----------------------------------------------
+ * motion_module.py:274-345 (VersatileAttention over the F frames of one spatial position);
+ * unit (b, p, head) reads rows (b*F + f)*HW + p at column offset head*d.  F <= 32. */
+int mc_tattn_fwd_f16(const void* q, const void* k, const void* v, int ld, void* o, int ldo, int B, int F,
+                     int HW, int heads, int d, float scale, void* stream);
+/* motionclone_functions.py:260-283 + torch.topk(k=1) of :79 -> top_val fp16 / top_idx u8, [B*HW, heads, F] */
+int mc_tattn_top1_f16(const void* q, const void* k, int ld, void* top_val, void* top_idx, int B, int F, int HW,
+                      int heads, int d, float scale, void* stream);
+/* motionclone_functions.py:85-100 for one module: loss[0] = mean((gather(P, idx) - ref)^2).
+ * unit_loss: float[B*HW*heads] workspace. */
+int mc_tattn_loss_f16(const void* q, const void* k, int ld, const void* ref_idx, const float* ref_val,
+                      float* unit_loss, float* loss, int B, int F, int HW, int heads, int d, float scale,
+                      void* stream);
+/* data-gradient of the attention (dO may be NULL) fused with the guidance seed
+ * dP[q, idx[q]] += seed_coef * (P[q, idx[q]] - ref[q]) (ref_idx may be NULL): motionclone_functions.py:236 */
+int mc_tattn_bwd_f16(const void* q, const void* k, const void* v, int ld, const void* dO, int lddo, void* dq,
+                     void* dk, void* dv, int ldg, const void* ref_idx, const float* ref_val, float seed_coef,
+                     int B, int F, int HW, int heads, int d, float scale, void* stream);
+int mc_reduce_sum_f32(const float* in, long n, float scale, float* out, void* stream);
+
+/* ---- element-wise glue ------------------------------------------------------------------------ */
+/* diffusers GEGLU: out = in[:, :D] * gelu(in[:, D:])  (attention.py:211, motion_module.py:209) */
+int mc_geglu_fwd_f16(const void* in, int ldi, void* out, int ldo, int M, int D, void* stream);
+int mc_geglu_bwd_f16(const void* dout, int lddo, const void* in, int ldi, void* din, int lddi, int M, int D,
+                     void* stream);
+/* out = sa*a + sb*b (b may be NULL) - residual / skip-gradient accumulation */
+int mc_add_f16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int M, int C, float sa,
+               float sb, void* stream);
+/* data-gradient of F.interpolate(nearest, 2x) (resnet.py:65): 2x2 sum-pool */
+int mc_sumpool2_f16(const void* in, int ldi, void* out, int ldo, int frames, int H, int W, int C,
+                    int accumulate, void* stream);
+/* [B, CL, F, H, W] latent <-> channels-last tokens (the only layout change on the path) */
+int mc_latent_to_cl_f16(const void* lat, void* out, int B, int CL, int F, int HW, int CP, void* stream);
+int mc_cl_to_latent_f16(const void* in, int ld, void* out, int out_f32, float scale, int B, int CL, int F,
+                        int HW, void* stream);
+/* diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) (unet.py:101,386-391) */
+int mc_timestep_embed_f16(const float* t, void* out, int B, int dim, void* stream);
+int mc_silu_f16(const void* in, void* out, long n, void* stream);
+/* eps = eps_c + cfg*(eps_c - eps_u) (motionclone_functions.py:239,255) followed by the guided DDIM
+ * update of schedule_customized_step (:326-389, eta = 0):
+ *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  eps' = eps - score_coef * score;
+ *   out = sqrt(a_prev) x0 + sqrt(1-a_prev) eps'.
+ * eps_c / eps_u channels-last [(f h w), ld]; x, score (fp32, may be NULL), out: [1, CL, F, H, W]. */
+int mc_cfg_ddim_step_f16(const void* eps_c, const void* eps_u, int ld, const void* x, const float* score,
+                         void* out, void* eps_out, float cfg, float sqrt_a_t, float sqrt_1m_a_t,
+                         float sqrt_a_prev, float sqrt_1m_a_prev, float score_coef, int CL, int F, int HW,
+                         void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MC_KERNELS_H */

@@ -1,0 +1,100 @@
+"""Build helpers for libmotionclone_hip.so (gfx950) and, for tests only, the host simulator build.
+
+`build_hip()` is what `__graft_entry__.build()` calls: one hipcc invocation per .hip source
+(cross-compiles without a GPU), linked in-tree so the .so travels with the repo snapshot.
+"""
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+REPO = os.path.dirname(HERE)
+SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
+HIP_LIB = os.path.join(CSRC, "libmotionclone_hip.so")
+EMU_DIR = os.path.join(REPO, "tests", "hipemu")
+EMU_LIB = os.path.join(EMU_DIR, "_build", "libmc_emu.so")
+
+
+def _stamp(paths, extra=""):
+    h = hashlib.sha1(extra.encode())
+    for p in sorted(paths):
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("command failed: %s\n%s" % (" ".join(cmd), r.stdout))
+    return r.stdout
+
+
+def _deps():
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "mc_common.hpp")]
+
+
+def build_hip(force=False, verbose=False):
+    """Compile every HIP source for gfx950 and link csrc/libmotionclone_hip.so."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+    stamp = _stamp(_deps(), " ".join(flags))
+    stamp_file = HIP_LIB + ".stamp"
+    if not force and os.path.exists(HIP_LIB) and os.path.exists(stamp_file):
+        if open(stamp_file).read() == stamp:
+            return HIP_LIB
+    objdir = os.path.join(CSRC, "build")
+    os.makedirs(objdir, exist_ok=True)
+
+    def one(src):
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        out = _run([hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
+        if verbose and out.strip():
+            print(out)
+        return obj
+
+    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
+        objs = list(ex.map(one, SOURCES))
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return HIP_LIB
+
+
+def build_emu(force=False):
+    """TEST ONLY: compile the same kernel sources for the host against tests/hipemu (no GPU needed)."""
+    cxx = os.environ.get("MC_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")
+    deps = _deps() + [os.path.join(EMU_DIR, "hip_emu.h"), os.path.join(EMU_DIR, "hip_emu.cpp")]
+    flags = ["-std=c++20", "-O2", "-mf16c", "-DMC_EMU", "-fPIC", "-I", EMU_DIR, "-I", CSRC,
+             "-Wno-unused-value", "-Wno-pass-failed"]
+    stamp = _stamp(deps, " ".join(flags))
+    stamp_file = EMU_LIB + ".stamp"
+    if not force and os.path.exists(EMU_LIB) and os.path.exists(stamp_file):
+        if open(stamp_file).read() == stamp:
+            return EMU_LIB
+    os.makedirs(os.path.dirname(EMU_LIB), exist_ok=True)
+    objdir = os.path.dirname(EMU_LIB)
+
+    def one(src):
+        obj = os.path.join(objdir, os.path.basename(src) + ".o")
+        lang = ["-x", "c++"] if src.endswith(".hip") else []
+        _run([cxx] + flags + lang + ["-c", src, "-o", obj])
+        return obj
+
+    srcs = [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(EMU_DIR, "hip_emu.cpp")]
+    with ThreadPoolExecutor(max_workers=8) as ex:
+        objs = list(ex.map(one, srcs))
+    _run([cxx, "-shared", "-fPIC", "-o", EMU_LIB] + objs + ["-lpthread"])
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return EMU_LIB
+
+
+if __name__ == "__main__":
+    if "--emu" in sys.argv:
+        print(build_emu(force="--force" in sys.argv))
+    else:
+        print(build_hip(force="--force" in sys.argv, verbose=True))

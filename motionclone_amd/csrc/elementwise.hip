@@ -1,0 +1,280 @@
+// HBM-bound glue of the guided DDIM step (§8a A12):
+// GEGLU (diffusers FeedForward used at attention.py:211 / motion_module.py:209),
+// strided adds, 2x2 sum-pool (data-gradient of the nearest-2x upsample of
+// resnet.py:65), latent <-> channels-last conversion, sinusoidal timestep
+// embedding (unet.py:386-392), SiLU, and the fused classifier-free-guidance +
+// guided DDIM update (motionclone_functions.py:239,255,326-389).
+#include "mc_common.hpp"
+
+namespace mc {
+
+__global__ void geglu_fwd_kernel(const half_t* in, int ldi, half_t* out, int ldo, int M, int D) {
+    const int VD = D / 8;
+    const long total = (long)M * VD;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long m = idx / VD;
+        int c = (int)(idx - m * VD) * 8;
+        half8_t h = ld8(in + m * ldi + c);
+        half8_t g = ld8(in + m * ldi + D + c);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = to_half((float)h[e] * gelu_f((float)g[e]));
+        st8(out + m * ldo + c, o);
+    }
+}
+
+__global__ void geglu_bwd_kernel(const half_t* dout, int lddo, const half_t* in, int ldi, half_t* din,
+                                 int lddi, int M, int D) {
+    const int VD = D / 8;
+    const long total = (long)M * VD;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long m = idx / VD;
+        int c = (int)(idx - m * VD) * 8;
+        half8_t h = ld8(in + m * ldi + c);
+        half8_t g = ld8(in + m * ldi + D + c);
+        half8_t d = ld8(dout + m * lddo + c);
+        half8_t oh, og;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float gv = (float)g[e], dv = (float)d[e];
+            oh[e] = to_half(dv * gelu_f(gv));
+            og[e] = to_half(dv * (float)h[e] * gelu_grad_f(gv));
+        }
+        st8(din + m * lddi + c, oh);
+        st8(din + m * lddi + D + c, og);
+    }
+}
+
+// out = sa * a + sb * b over an [M][C] window of strided matrices (b may be null)
+__global__ void add_kernel(const half_t* a, int lda, const half_t* b, int ldb, half_t* out, int ldo, int M,
+                           int C, float sa, float sb) {
+    const int VC = C / 8;
+    const long total = (long)M * VC;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long m = idx / VC;
+        int c = (int)(idx - m * VC) * 8;
+        half8_t x = ld8(a + m * lda + c);
+        half8_t o;
+        if (b) {
+            half8_t y = ld8(b + m * ldb + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = to_half(sa * (float)x[e] + sb * (float)y[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = to_half(sa * (float)x[e]);
+        }
+        st8(out + m * ldo + c, o);
+    }
+}
+
+// out[f, y, x, :] (+)= sum_{a,b in 0..1} in[f, 2y+a, 2x+b, :]
+__global__ void sumpool2_kernel(const half_t* in, int ldi, half_t* out, int ldo, int frames, int H, int W,
+                                int C, int accumulate) {
+    const int VC = C / 8;
+    const long total = (long)frames * H * W * VC;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        long tok = idx / VC;
+        int c = (int)(idx - tok * VC) * 8;
+        int x = (int)(tok % W);
+        long t2 = tok / W;
+        int y = (int)(t2 % H);
+        long f = t2 / H;
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        if (accumulate) {
+            half8_t p = ld8(out + tok * ldo + c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] = (float)p[e];
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                long src = (f * 2 * H + 2 * y + a) * 2 * W + 2 * x + b;
+                half8_t v = ld8(in + src * ldi + c);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = to_half(acc[e]);
+        st8(out + tok * ldo + c, o);
+    }
+}
+
+// [B, CL, F, H, W] fp16 -> [(b f h w), CP] channels-last, channels >= CL zero-filled
+__global__ void latent_to_cl_kernel(const half_t* lat, half_t* out, int B, int CL, int F, int HW, int CP) {
+    const long total = (long)B * F * HW * CP;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int c = (int)(idx % CP);
+        long tok = idx / CP;
+        int p = (int)(tok % HW);
+        long bf = tok / HW;
+        int f = (int)(bf % F);
+        int b = (int)(bf / F);
+        half_t v = (half_t)0.f;
+        if (c < CL) v = lat[(((size_t)b * CL + c) * F + f) * HW + p];
+        out[idx] = v;
+    }
+}
+
+// channels-last [(b f h w), ld] (first CL channels) -> [B, CL, F, H, W]; fp16 or fp32 output, scaled
+__global__ void cl_to_latent_kernel(const half_t* in, int ld, void* out, int out_f32, float scale, int B, int CL,
+                                    int F, int HW) {
+    const long total = (long)B * CL * F * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int p = (int)(idx % HW);
+        long r = idx / HW;
+        int f = (int)(r % F);
+        r /= F;
+        int c = (int)(r % CL);
+        int b = (int)(r / CL);
+        float v = (float)in[(((size_t)b * F + f) * HW + p) * ld + c] * scale;
+        if (out_f32)
+            reinterpret_cast<float*>(out)[idx] = v;
+        else
+            reinterpret_cast<half_t*>(out)[idx] = to_half(v);
+    }
+}
+
+// diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
+__global__ void timestep_embed_kernel(const float* t, half_t* out, int B, int dim) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * dim) return;
+    int b = idx / dim, i = idx % dim;
+    int half_dim = dim / 2;
+    int j = i < half_dim ? i : i - half_dim;
+    float freq = expf(-logf(10000.0f) * (float)j / (float)half_dim);
+    float a = t[b] * freq;
+    out[idx] = (half_t)(i < half_dim ? cosf(a) : sinf(a));
+}
+
+__global__ void silu_kernel(const half_t* in, half_t* out, long n) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += (long)gridDim.x * blockDim.x)
+        out[idx] = to_half(silu_f((float)in[idx]));
+}
+
+struct DdimCoef {
+    float cfg;            // classifier-free guidance scale s in eps_c + s*(eps_c - eps_u)
+    float sqrt_a_t;       // sqrt(alpha_bar_t)
+    float sqrt_1m_a_t;    // sqrt(1 - alpha_bar_t)
+    float sqrt_a_prev;    // sqrt(alpha_bar_prev)
+    float sqrt_1m_a_prev; // sqrt(1 - alpha_bar_prev)   (eta = 0)
+    float score_coef;     // guidance_scale * sqrt(1 - alpha_bar_t) * (1 / grad_scale)
+};
+
+// eps_c/eps_u: channels-last [(f h w), ld] (first CL channels); x, score, out: [1, CL, F, H, W]
+__global__ void cfg_ddim_kernel(const half_t* eps_c, const half_t* eps_u, int ld, const half_t* x,
+                                const float* score, half_t* out, half_t* eps_out, DdimCoef k, int CL, int F,
+                                int HW) {
+    const long total = (long)CL * F * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int p = (int)(idx % HW);
+        long r = idx / HW;
+        int f = (int)(r % F);
+        int c = (int)(r / F);
+        size_t src = ((size_t)f * HW + p) * ld + c;
+        float ec = (float)eps_c[src], eu = (float)eps_u[src];
+        float eps = ec + k.cfg * (ec - eu);
+        float xv = (float)x[idx];
+        float x0 = (xv - k.sqrt_1m_a_t * eps) / k.sqrt_a_t;     // uses the un-guided eps (quirk A12)
+        float e2 = eps;
+        if (score) e2 -= k.score_coef * score[idx];
+        out[idx] = to_half(k.sqrt_a_prev * x0 + k.sqrt_1m_a_prev * e2);
+        if (eps_out) eps_out[idx] = to_half(eps);
+    }
+}
+
+static inline int ew_blocks(long total) {
+    long b = (total + 255) / 256;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (int)b;
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+extern "C" int mc_geglu_fwd_f16(const void* in, int ldi, void* out, int ldo, int M, int D, void* stream) {
+    if (M <= 0 || D <= 0 || D % 8 || ldi % 8 || ldo % 8) return MC_ERR_SHAPE;
+    MC_LAUNCH(geglu_fwd_kernel, dim3(ew_blocks((long)M * D / 8)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)in, ldi, (half_t*)out, ldo, M, D);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_geglu_bwd_f16(const void* dout, int lddo, const void* in, int ldi, void* din, int lddi,
+                                int M, int D, void* stream) {
+    if (M <= 0 || D <= 0 || D % 8 || ldi % 8 || lddo % 8 || lddi % 8) return MC_ERR_SHAPE;
+    MC_LAUNCH(geglu_bwd_kernel, dim3(ew_blocks((long)M * D / 8)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)dout, lddo, (const half_t*)in, ldi, (half_t*)din, lddi, M, D);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_add_f16(const void* a, int lda, const void* b, int ldb, void* out, int ldo, int M, int C,
+                          float sa, float sb, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || lda % 8 || ldo % 8 || (b && ldb % 8)) return MC_ERR_SHAPE;
+    MC_LAUNCH(add_kernel, dim3(ew_blocks((long)M * C / 8)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)a, lda, (const half_t*)b, ldb, (half_t*)out, ldo, M, C, sa, sb);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_sumpool2_f16(const void* in, int ldi, void* out, int ldo, int frames, int H, int W, int C,
+                               int accumulate, void* stream) {
+    if (frames <= 0 || H <= 0 || W <= 0 || C % 8 || ldi % 8 || ldo % 8) return MC_ERR_SHAPE;
+    MC_LAUNCH(sumpool2_kernel, dim3(ew_blocks((long)frames * H * W * C / 8)), dim3(256), 0,
+              (hipStream_t)stream, (const half_t*)in, ldi, (half_t*)out, ldo, frames, H, W, C, accumulate);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_latent_to_cl_f16(const void* lat, void* out, int B, int CL, int F, int HW, int CP,
+                                   void* stream) {
+    if (B <= 0 || CL <= 0 || F <= 0 || HW <= 0 || CP < CL) return MC_ERR_SHAPE;
+    MC_LAUNCH(latent_to_cl_kernel, dim3(ew_blocks((long)B * F * HW * CP)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)lat, (half_t*)out, B, CL, F, HW, CP);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_cl_to_latent_f16(const void* in, int ld, void* out, int out_f32, float scale, int B, int CL,
+                                   int F, int HW, void* stream) {
+    if (B <= 0 || CL <= 0 || F <= 0 || HW <= 0 || ld < CL) return MC_ERR_SHAPE;
+    MC_LAUNCH(cl_to_latent_kernel, dim3(ew_blocks((long)B * CL * F * HW)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)in, ld, out, out_f32, scale, B, CL, F, HW);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_timestep_embed_f16(const float* t, void* out, int B, int dim, void* stream) {
+    if (B <= 0 || dim <= 0 || dim % 2) return MC_ERR_SHAPE;
+    MC_LAUNCH(timestep_embed_kernel, dim3((B * dim + 255) / 256), dim3(256), 0, (hipStream_t)stream, t,
+              (half_t*)out, B, dim);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_silu_f16(const void* in, void* out, long n, void* stream) {
+    if (n <= 0) return MC_ERR_SHAPE;
+    MC_LAUNCH(silu_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in,
+              (half_t*)out, n);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_cfg_ddim_step_f16(const void* eps_c, const void* eps_u, int ld, const void* x,
+                                    const float* score, void* out, void* eps_out, float cfg, float sqrt_a_t,
+                                    float sqrt_1m_a_t, float sqrt_a_prev, float sqrt_1m_a_prev,
+                                    float score_coef, int CL, int F, int HW, void* stream) {
+    if (CL <= 0 || F <= 0 || HW <= 0 || ld < CL) return MC_ERR_SHAPE;
+    DdimCoef k{cfg, sqrt_a_t, sqrt_1m_a_t, sqrt_a_prev, sqrt_1m_a_prev, score_coef};
+    MC_LAUNCH(cfg_ddim_kernel, dim3(ew_blocks((long)CL * F * HW)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)eps_c, (const half_t*)eps_u, ld, (const half_t*)x, score, (half_t*)out,
+              (half_t*)eps_out, k, CL, F, HW);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_version(void) { return 1; }

@@ -1,0 +1,292 @@
+// MFMA GEMM family for the UNet3D hot path:
+//   C[M,N] = alpha * (A[M,K] . W[N,K]^T) + bias[batch(m)][n] + R[m][n]
+// with the A operand produced on the fly by one of five "gather" modes so that
+// nn.Linear, 1x1 conv, 3x3 conv (stride 1 / stride 2 / fused nearest-2x upsample),
+// their data-gradients, and the skip-connection concat all run through ONE kernel
+// on channels-last [frames, H, W, C] fp16 activations:
+//   DENSE   : A row m = token m, optional second source for the channel concat
+//   CONV_S1 : 3x3, stride 1, pad 1           (reference resnet.py:148,168; unet.py:98,249)
+//   CONV_S2 : 3x3, stride 2, pad 1           (reference resnet.py:94)
+//   CONV_UP : 3x3 on a nearest-2x upsampled source, never materialised (resnet.py:65,78)
+//   TCONV_S2: data-gradient of CONV_S2 (scatter written as a gather)
+// K is ordered tap-major / channel-minor (k = tap*Ctot + c), so a 64-wide K tile
+// is one contiguous 128-byte run of channels of one (shifted) pixel.
+//
+// Tiling (gfx950): 256 threads = 4 waves as 2x2; block tile BMxBN in {128x128, 64x64},
+// BK = 64; v_mfma_f32_32x32x16_f16 with the weight tile as the MFMA "A" operand so
+// that each lane ends up with 4 consecutive output channels of one token (8-byte
+// stores, 8-byte bias/residual loads).  Operand tiles are staged global -> VGPR ->
+// LDS (16 B per lane, XOR-swizzled 16-byte slots: conflict-free ds_read_b128),
+// double-buffered, one barrier per K tile, next tile's global loads issued before
+// the current tile's MFMAs.
+#include "mc_common.hpp"
+
+namespace mc {
+
+enum GemmMode { DENSE = 0, CONV_S1 = 1, CONV_S2 = 2, CONV_UP = 3, TCONV_S2 = 4 };
+
+struct GemmParams {
+    const half_t* A;
+    const half_t* A2;
+    const half_t* W;
+    half_t* C;
+    const half_t* R;
+    const float* bias;
+    int M, N, K;
+    int lda, lda2, ldc, ldr;
+    int c1;     // channels taken from A; the rest (ctot - c1) come from A2
+    int ctot;   // channels per tap (conv) or K (dense)
+    int Hs, Ws; // source grid (per frame)
+    int Ho, Wo; // output grid (per frame)
+    int rows_per_batch;
+    float alpha;
+};
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ int lds_off(int row, int v) {
+    // byte offset of 16-byte slot v (0..7) of a 128-byte row; slots XOR-swizzled by (row>>1)&7
+    return row * 128 + ((v ^ ((row >> 1) & 7)) << 4);
+}
+
+template <int MODE, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
+    constexpr int RA = BM / 32;  // A rows staged per thread
+    constexpr int RW = BN / 32;
+    constexpr int TM = BM / 64;  // 32x32 MFMA tiles per wave along M
+    constexpr int TN = BN / 64;
+    MC_DYN_SMEM(smem);
+    char* sA = smem;                       // [2][BM][128 B]
+    char* sW = smem + 2 * BM * 128;        // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int m0 = blockIdx.y * BM;
+    const int n0 = blockIdx.x * BN;
+    const int vcol = tid & 7;
+    const int rbase = tid >> 3;  // 0..31
+
+    // ---- per-thread row descriptors (fixed over the K loop) ----
+    int a_valid[RA];
+    int a_pix[RA];  // DENSE: row index m; conv: frame * Hs * Ws
+    int a_oy[RA], a_ox[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int m = m0 + rbase + 32 * i;
+        a_valid[i] = m < p.M;
+        if (MODE == DENSE) {
+            a_pix[i] = m;
+            a_oy[i] = 0;
+            a_ox[i] = 0;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int fr = m / hw;
+            int rem = m - fr * hw;
+            int oy = rem / p.Wo;
+            a_pix[i] = fr * p.Hs * p.Ws;
+            a_oy[i] = oy;
+            a_ox[i] = rem - oy * p.Wo;
+        }
+    }
+    const half_t* w_ptr[RW];
+    int w_valid[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        int n = n0 + rbase + 32 * i;
+        w_valid[i] = n < p.N;
+        w_ptr[i] = p.W + (size_t)(w_valid[i] ? n : 0) * p.K + vcol * 8;
+    }
+
+    half8_t ra[RA], rw[RW];
+
+    auto load_tiles = [&](int kt) {
+        const int k0 = kt * BK;
+        int tap = 0, c0 = k0;
+        if (MODE != DENSE) {
+            tap = k0 / p.ctot;
+            c0 = k0 - tap * p.ctot;
+        }
+        const half_t* src = p.A;
+        int ld = p.lda;
+        int cc = c0;
+        if (c0 >= p.c1) {
+            src = p.A2;
+            ld = p.lda2;
+            cc = c0 - p.c1;
+        }
+        const int ky = tap / 3, kx = tap - 3 * (tap / 3);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            bool ok = a_valid[i];
+            size_t row;
+            if (MODE == DENSE) {
+                row = (size_t)a_pix[i];
+            } else {
+                int iy, ix;
+                if (MODE == CONV_S1) {
+                    iy = a_oy[i] + ky - 1;
+                    ix = a_ox[i] + kx - 1;
+                    ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                } else if (MODE == CONV_S2) {
+                    iy = 2 * a_oy[i] + ky - 1;
+                    ix = 2 * a_ox[i] + kx - 1;
+                    ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                } else if (MODE == CONV_UP) {
+                    int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;  // on the upsampled grid
+                    ok = ok && uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                    iy = uy >> 1;
+                    ix = ux >> 1;
+                } else {  // TCONV_S2: y = 2*sy + ky - 1  <=>  sy = (y + 1 - ky) / 2
+                    int ty = a_oy[i] + 1 - ky, tx = a_ox[i] + 1 - kx;
+                    ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
+                    iy = ty >> 1;
+                    ix = tx >> 1;
+                    ok = ok && iy < p.Hs && ix < p.Ws;
+                }
+                row = (size_t)(a_pix[i] + iy * p.Ws + ix);
+            }
+            ra[i] = ok ? ld8(src + row * ld + cc + vcol * 8) : zero8();
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) rw[i] = w_valid[i] ? ld8(w_ptr[i] + k0) : zero8();
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            int r = rbase + 32 * i;
+            *reinterpret_cast<half8_t*>(sA + buf * BM * 128 + lds_off(r, vcol)) = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            int r = rbase + 32 * i;
+            *reinterpret_cast<half8_t*>(sW + buf * BN * 128 + lds_off(r, vcol)) = rw[i];
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wm0 = (wave & 1) * (BM / 2);
+    const int wn0 = (wave >> 1) * (BN / 2);
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int nk = p.K / BK;
+    load_tiles(0);
+    store_tiles(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_tiles(kt + 1);
+        const char* bA = sA + buf * BM * 128;
+        const char* bW = sW + buf * BN * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8_t fa[TM], fw[TN];
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                fa[j] = *reinterpret_cast<const half8_t*>(bA + lds_off(wm0 + 32 * j + l31, 2 * ks + lhi));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                fw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off(wn0 + 32 * i + l31, 2 * ks + lhi));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(fw[i], fa[j], acc[i][j]);
+        }
+        if (kt + 1 < nk) store_tiles(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds D[n = nb + (r&3) + 8*(r>>2) + 4*lhi][m = mb + l31] ----
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = m0 + wm0 + 32 * j + l31;
+        if (m >= p.M) continue;
+        const float* brow = p.bias ? p.bias + (size_t)(m / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn0 + 32 * i + 8 * q + 4 * lhi;
+                if (n >= p.N) continue;
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (brow) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(brow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                }
+                if (p.R) {
+                    half4_t r = ld4(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+                }
+                half4_t o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+                st4(p.C + (size_t)m * p.ldc + n, o);
+            }
+        }
+    }
+}
+
+template <int MODE>
+static int launch_mode(const GemmParams& p, int small_tile, hipStream_t stream) {
+    if (small_tile) {
+        dim3 grid((p.N + 63) / 64, (p.M + 63) / 64);
+        MC_LAUNCH((gemm_kernel<MODE, 64, 64>), grid, dim3(256), 2 * (64 + 64) * 128, stream, p);
+    } else {
+        dim3 grid((p.N + 127) / 128, (p.M + 127) / 128);
+        MC_LAUNCH((gemm_kernel<MODE, 128, 128>), grid, dim3(256), 2 * (128 + 128) * 128, stream, p);
+    }
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
+                           const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
+                           int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
+                           int rows_per_batch, float alpha, int tile, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return MC_ERR_SHAPE;
+    if (K % BK || N % 4 || ldc % 4 || (R && (ldr % 4))) return MC_ERR_SHAPE;
+    if (lda % 8 || (A2 && lda2 % 8)) return MC_ERR_SHAPE;
+    if (mode < 0 || mode > 4) return MC_ERR_UNSUPPORTED;
+    if (mode == DENSE) ctot = K;
+    if (ctot <= 0 || ctot % BK || c1 % BK || c1 > ctot) return MC_ERR_SHAPE;
+    if (c1 < ctot && !A2) return MC_ERR_SHAPE;
+    if (mode != DENSE) {
+        if (K != 9 * ctot || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return MC_ERR_SHAPE;
+        if (M % (Ho * Wo)) return MC_ERR_SHAPE;
+    }
+    if (rows_per_batch <= 0) rows_per_batch = M;
+    GemmParams p;
+    p.A = (const half_t*)A; p.A2 = (const half_t*)A2; p.W = (const half_t*)W;
+    p.C = (half_t*)C; p.R = (const half_t*)R; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
+    p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
+    p.rows_per_batch = rows_per_batch; p.alpha = alpha;
+    int small_tile = tile == 64;
+    if (tile == 0) {
+        // heuristic: fall to 64x64 tiles when 128x128 would leave most of the 256 CUs idle
+        long big = (long)((M + 127) / 128) * ((N + 127) / 128);
+        small_tile = big < 256;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    switch (mode) {
+        case DENSE: return launch_mode<DENSE>(p, small_tile, s);
+        case CONV_S1: return launch_mode<CONV_S1>(p, small_tile, s);
+        case CONV_S2: return launch_mode<CONV_S2>(p, small_tile, s);
+        case CONV_UP: return launch_mode<CONV_UP>(p, small_tile, s);
+        default: return launch_mode<TCONV_S2>(p, small_tile, s);
+    }
+}

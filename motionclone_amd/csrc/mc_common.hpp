@@ -1,0 +1,125 @@
+// Common device-side vocabulary for the MotionClone gfx950 kernels.
+//
+// Every kernel in this directory is written against the small set of wave-level
+// primitives declared here (64-lane shuffles, two MFMA shapes, vector types).
+// On the product build (hipcc --offload-arch=gfx950) they lower to the CDNA4
+// builtins.  When MC_EMU is defined (tests/hipemu only, never shipped) the same
+// sources are compiled for the host against a lane-accurate fiber simulator so
+// that index math / barrier placement can be exercised without a GPU.
+#pragma once
+
+#ifdef MC_EMU
+#include "hip_emu.h"
+#else
+#include <hip/hip_runtime.h>
+#endif
+#include <stdint.h>
+#include <algorithm>
+#include <cmath>
+
+namespace mc {
+
+typedef _Float16 half_t;
+typedef _Float16 half2_t __attribute__((ext_vector_type(2)));
+typedef _Float16 half4_t __attribute__((ext_vector_type(4)));
+typedef _Float16 half8_t __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int kWave = 64;
+
+#ifdef MC_EMU
+// ---- simulator lowering -------------------------------------------------------
+__device__ inline float shfl_xor(float v, int m) { return hipemu::shfl_xor(v, m); }
+__device__ inline int shfl_xor(int v, int m) { return hipemu::shfl_xor(v, m); }
+__device__ inline float shfl(float v, int src) { return hipemu::shfl(v, src); }
+__device__ inline int shfl(int v, int src) { return hipemu::shfl(v, src); }
+__device__ inline f32x4 mfma16(half4_t a, half4_t b, f32x4 c) { return hipemu::mfma_16x16x16(a, b, c); }
+__device__ inline f32x16 mfma32(half8_t a, half8_t b, f32x16 c) { return hipemu::mfma_32x32x16(a, b, c); }
+__device__ inline float fast_exp(float x) { return expf(x); }
+__device__ inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
+#define MC_DYN_SMEM(name) char* name = hipemu::dyn_smem()
+#define MC_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipemu::launch((grid), (block), (smem), [=]() { kern(__VA_ARGS__); })
+#define MC_LAST_ERROR() 0
+template <class K>
+static inline void allow_big_smem(K, size_t) {}
+#else
+// ---- gfx950 lowering ----------------------------------------------------------
+__device__ __forceinline__ float shfl_xor(float v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ int shfl_xor(int v, int m) { return __shfl_xor(v, m, 64); }
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ int shfl(int v, int src) { return __shfl(v, src, 64); }
+// D[16x16] += A[16x16] * B[16x16]; lane l: a = A[l&15][4*(l>>4)+j], b = B[4*(l>>4)+j][l&15],
+// c[i] = C[4*(l>>4)+i][l&15].
+__device__ __forceinline__ f32x4 mfma16(half4_t a, half4_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, c, 0, 0, 0);
+}
+// D[32x32] += A[32x16] * B[16x32]; lane l: a = A[l&31][8*(l>>5)+j], b = B[8*(l>>5)+j][l&31],
+// c[r] = C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
+__device__ __forceinline__ f32x16 mfma32(half8_t a, half8_t b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
+__device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
+#define MC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
+#define MC_LAUNCH(kern, grid, block, smem, stream, ...) \
+    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
+#define MC_LAST_ERROR() ((int)hipGetLastError())
+// dynamic LDS above 64 KiB has to be opted into per kernel (gfx950 has 160 KiB per CU)
+template <class K>
+static inline void allow_big_smem(K kern, size_t bytes) {
+    if (bytes > 64 * 1024)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)bytes);
+}
+#endif
+
+// reductions across the 64 lanes of a wave
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += shfl_xor(v, m);
+    return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v = fmaxf(v, shfl_xor(v, m));
+    return v;
+}
+
+__device__ inline float silu_f(float x) { return x / (1.0f + fast_exp(-x)); }
+// d/dx silu(x) = s + x*s*(1-s), s = sigmoid(x)
+__device__ inline float silu_grad_f(float x) {
+    float s = 1.0f / (1.0f + fast_exp(-x));
+    return s * (1.0f + x * (1.0f - s));
+}
+__device__ inline float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ inline float gelu_grad_f(float x) {
+    float cdf = 0.5f * (1.0f + erff(x * 0.70710678118654752f));
+    float pdf = 0.39894228040143268f * expf(-0.5f * x * x);
+    return cdf + x * pdf;
+}
+
+__device__ inline half8_t ld8(const half_t* p) { return *reinterpret_cast<const half8_t*>(p); }
+__device__ inline void st8(half_t* p, half8_t v) { *reinterpret_cast<half8_t*>(p) = v; }
+__device__ inline half4_t ld4(const half_t* p) { return *reinterpret_cast<const half4_t*>(p); }
+__device__ inline void st4(half_t* p, half4_t v) { *reinterpret_cast<half4_t*>(p) = v; }
+__device__ inline half8_t zero8() { half8_t z; for (int i = 0; i < 8; ++i) z[i] = (half_t)0.0f; return z; }
+__device__ inline half4_t zero4() { half4_t z; for (int i = 0; i < 4; ++i) z[i] = (half_t)0.0f; return z; }
+__device__ inline f32x4 fzero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// saturating float -> half (fp16 max 65504); keeps NaN out of downstream tensors on overflow
+__device__ inline half_t to_half(float x) {
+    x = fminf(fmaxf(x, -65504.0f), 65504.0f);
+    return (half_t)x;
+}
+
+}  // namespace mc
+
+// status codes returned through the C ABI (include/mc_kernels.h)
+#define MC_OK 0
+#define MC_ERR_SHAPE -1
+#define MC_ERR_UNSUPPORTED -2
+#define MC_ERR_LAUNCH -3

@@ -1,0 +1,450 @@
+// GroupNorm(32 groups)[+SiLU] and LayerNorm, forward and data-gradient, on
+// channels-last [frames, HW, C] fp16 activations.
+// Reference semantics: resnet.py:21-29,186-187,197-203 (eps 1e-5, +SiLU),
+// attention.py:61,105 / motion_module.py:112,145 (eps 1e-6), LayerNorm at
+// attention.py:189,206,212 and motion_module.py:204,210; the sinusoidal temporal
+// position table (motion_module.py:237-246) is added in the LayerNorm epilogue.
+//
+// All of these are HBM-bound: 16 B per lane loads, fp32 statistics, the skip
+// concat of the up blocks is read as two sources instead of being materialised.
+#include "mc_common.hpp"
+
+namespace mc {
+
+struct GnSrc {
+    const half_t* a;
+    const half_t* b;
+    int lda, ldb;
+    int c1, ctot;  // channels from a; total
+    int hw;        // tokens per frame
+    int cpg;       // channels per group (ctot / 32)
+};
+
+__device__ __forceinline__ half8_t gn_load(const GnSrc& s, size_t tok, int c) {
+    return c < s.c1 ? ld8(s.a + tok * s.lda + c) : ld8(s.b + tok * s.ldb + (c - s.c1));
+}
+
+// ---- pass 1 of forward stats: per (frame, chunk, group) sum / sum of squares -------------
+// grid (nchunk, frames), block = VC * R threads (VC = ctot/8 vector columns)
+__global__ void gn_partial_kernel(GnSrc s, int R, int nchunk, float* partial) {
+    MC_DYN_SMEM(smem);
+    float* ssum = reinterpret_cast<float*>(smem);  // [R][ctot]
+    float* ssq = ssum + R * s.ctot;
+    const int VC = s.ctot / 8;
+    const int t = threadIdx.x;
+    const int col = t % VC, r = t / VC;
+    const int frame = blockIdx.y, chunk = blockIdx.x;
+    const int per = (s.hw + nchunk - 1) / nchunk;
+    const int t0 = chunk * per;
+    const int t1 = min(s.hw, t0 + per);
+    float sum[8], sq[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
+    if (r < R) {
+        for (int tk = t0 + r; tk < t1; tk += R) {
+            half8_t v = gn_load(s, (size_t)frame * s.hw + tk, col * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float f = (float)v[e];
+                sum[e] += f;
+                sq[e] += f * f;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            ssum[r * s.ctot + col * 8 + e] = sum[e];
+            ssq[r * s.ctot + col * 8 + e] = sq[e];
+        }
+    }
+    __syncthreads();
+    if (t < 32) {
+        float a = 0.f, b = 0.f;
+        for (int rr = 0; rr < R; ++rr)
+            for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) {
+                a += ssum[rr * s.ctot + c];
+                b += ssq[rr * s.ctot + c];
+            }
+        float* o = partial + ((size_t)(frame * nchunk + chunk) * 32 + t) * 2;
+        o[0] = a;
+        o[1] = b;
+    }
+}
+
+// mode 0: (sum, sumsq) -> (mean, rstd);  mode 1: (s1, s2) -> (s1/n, s2/n)
+__global__ void gn_finalize_kernel(const float* partial, float* stats, int frames, int nchunk, float n,
+                                   float eps, int mode) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= frames * 32) return;
+    int frame = i / 32, g = i % 32;
+    float a = 0.f, b = 0.f;
+    for (int c = 0; c < nchunk; ++c) {
+        const float* q = partial + ((size_t)(frame * nchunk + c) * 32 + g) * 2;
+        a += q[0];
+        b += q[1];
+    }
+    if (mode == 0) {
+        float mean = a / n;
+        float var = fmaxf(b / n - mean * mean, 0.f);
+        stats[i * 2] = mean;
+        stats[i * 2 + 1] = 1.0f / sqrtf(var + eps);
+    } else {
+        stats[i * 2] = a / n;
+        stats[i * 2 + 1] = b / n;
+    }
+}
+
+// y = (x - mean) * rstd * gamma + beta, optional SiLU; out is [tokens][ctot] (ld = ldo)
+__global__ void gn_apply_kernel(GnSrc s, const float* stats, const float* gamma, const float* beta,
+                                half_t* out, int ldo, long total_vec, int silu) {
+    const int VC = s.ctot / 8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec;
+         idx += (long)gridDim.x * blockDim.x) {
+        long tok = idx / VC;
+        int c0 = (int)(idx - tok * VC) * 8;
+        int frame = (int)(tok / s.hw);
+        half8_t v = gn_load(s, (size_t)tok, c0);
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int c = c0 + e;
+            const float* st = stats + ((size_t)frame * 32 + c / s.cpg) * 2;
+            float y = ((float)v[e] - st[0]) * st[1] * gamma[c] + beta[c];
+            if (silu) y = silu_f(y);
+            o[e] = to_half(y);
+        }
+        st8(out + (size_t)tok * ldo + c0, o);
+    }
+}
+
+// ---- backward pass 1: per (frame, chunk, group) sums of dxhat and dxhat*xhat ---------------
+__global__ void gn_bwd_partial_kernel(GnSrc s, const half_t* dz, int lddz, const float* stats,
+                                      const float* gamma, const float* beta, int silu, int R, int nchunk,
+                                      float* partial) {
+    MC_DYN_SMEM(smem);
+    float* s1 = reinterpret_cast<float*>(smem);
+    float* s2 = s1 + R * s.ctot;
+    const int VC = s.ctot / 8;
+    const int t = threadIdx.x;
+    const int col = t % VC, r = t / VC;
+    const int frame = blockIdx.y, chunk = blockIdx.x;
+    const int per = (s.hw + nchunk - 1) / nchunk;
+    const int t0 = chunk * per;
+    const int t1 = min(s.hw, t0 + per);
+    float a[8], b[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[e] = b[e] = 0.f;
+    if (r < R) {
+        float mean[8], rstd[8], gm[8], bt[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int c = col * 8 + e;
+            const float* st = stats + ((size_t)frame * 32 + c / s.cpg) * 2;
+            mean[e] = st[0];
+            rstd[e] = st[1];
+            gm[e] = gamma[c];
+            bt[e] = beta[c];
+        }
+        for (int tk = t0 + r; tk < t1; tk += R) {
+            size_t tok = (size_t)frame * s.hw + tk;
+            half8_t x = gn_load(s, tok, col * 8);
+            half8_t g = ld8(dz + tok * lddz + col * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float xh = ((float)x[e] - mean[e]) * rstd[e];
+                float dy = (float)g[e];
+                if (silu) dy *= silu_grad_f(xh * gm[e] + bt[e]);
+                float dxh = dy * gm[e];
+                a[e] += dxh;
+                b[e] += dxh * xh;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            s1[r * s.ctot + col * 8 + e] = a[e];
+            s2[r * s.ctot + col * 8 + e] = b[e];
+        }
+    }
+    __syncthreads();
+    if (t < 32) {
+        float x = 0.f, y = 0.f;
+        for (int rr = 0; rr < R; ++rr)
+            for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) {
+                x += s1[rr * s.ctot + c];
+                y += s2[rr * s.ctot + c];
+            }
+        float* o = partial + ((size_t)(frame * nchunk + chunk) * 32 + t) * 2;
+        o[0] = x;
+        o[1] = y;
+    }
+}
+
+// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); optional accumulate into dx
+__global__ void gn_bwd_apply_kernel(GnSrc s, const half_t* dz, int lddz, const float* stats,
+                                    const float* bstats, const float* gamma, const float* beta, int silu,
+                                    half_t* dx, int lddx, long total_vec, int accumulate) {
+    const int VC = s.ctot / 8;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec;
+         idx += (long)gridDim.x * blockDim.x) {
+        long tok = idx / VC;
+        int c0 = (int)(idx - tok * VC) * 8;
+        int frame = (int)(tok / s.hw);
+        half8_t x = gn_load(s, (size_t)tok, c0);
+        half8_t g = ld8(dz + (size_t)tok * lddz + c0);
+        half8_t o;
+        half8_t prev;
+        if (accumulate) prev = ld8(dx + (size_t)tok * lddx + c0);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            int c = c0 + e;
+            size_t gi = ((size_t)frame * 32 + c / s.cpg) * 2;
+            float mean = stats[gi], rstd = stats[gi + 1];
+            float m1 = bstats[gi], m2 = bstats[gi + 1];
+            float xh = ((float)x[e] - mean) * rstd;
+            float dy = (float)g[e];
+            if (silu) dy *= silu_grad_f(xh * gamma[c] + beta[c]);
+            float v = rstd * (dy * gamma[c] - m1 - xh * m2);
+            if (accumulate) v += (float)prev[e];
+            o[e] = to_half(v);
+        }
+        st8(dx + (size_t)tok * lddx + c0, o);
+    }
+}
+
+// ---- LayerNorm: one wave per row, row kept in registers ----------------------------------
+template <int NV>
+__global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* x, int ldx, half_t* y, int ldy,
+                                                      const float* gamma, const float* beta,
+                                                      const float* pe, int hw, int nframes_pe,
+                                                      float* stats, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool live = row < M;
+    const int nvec = C / 8;
+    half8_t v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int vi = lane + 64 * i;
+        if (live && vi < nvec) {
+            v[i] = ld8(x + (size_t)row * ldx + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        } else {
+            v[i] = zero8();
+        }
+    }
+    sum = wave_sum(sum);
+    const float mean = sum / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int vi = lane + 64 * i;
+        if (vi < nvec) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float d = (float)v[i][e] - mean;
+                sq += d * d;
+            }
+        }
+    }
+    sq = wave_sum(sq);
+    const float rstd = 1.0f / sqrtf(sq / C + eps);
+    if (!live) return;
+    if (lane == 0 && stats) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
+    }
+    const float* perow = pe ? pe + (size_t)((row / hw) % nframes_pe) * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int vi = lane + 64 * i;
+        if (vi < nvec) {
+            half8_t o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                int c = vi * 8 + e;
+                float t = ((float)v[i][e] - mean) * rstd * gamma[c] + beta[c];
+                if (perow) t += perow[c];
+                o[e] = to_half(t);
+            }
+            st8(y + (size_t)row * ldy + vi * 8, o);
+        }
+    }
+}
+
+// dx = rstd * (g - mean(g) - xhat * mean(g*xhat)) [+ add], g = dy * gamma
+template <int NV>
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const half_t* dy, int lddy, const half_t* x, int ldx,
+                                                      const float* stats, const float* gamma,
+                                                      const half_t* add, int ldadd, half_t* dx, int lddx,
+                                                      int M, int C) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    const bool live = row < M;
+    const int nvec = C / 8;
+    const float mean = live ? stats[(size_t)row * 2] : 0.f;
+    const float rstd = live ? stats[(size_t)row * 2 + 1] : 0.f;
+    float g[NV][8], xh[NV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int vi = lane + 64 * i;
+        if (live && vi < nvec) {
+            half8_t xv = ld8(x + (size_t)row * ldx + vi * 8);
+            half8_t dv = ld8(dy + (size_t)row * lddy + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                xh[i][e] = ((float)xv[e] - mean) * rstd;
+                g[i][e] = (float)dv[e] * gamma[vi * 8 + e];
+                s1 += g[i][e];
+                s2 += g[i][e] * xh[i][e];
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xh[i][e] = g[i][e] = 0.f;
+        }
+    }
+    s1 = wave_sum(s1) / C;
+    s2 = wave_sum(s2) / C;
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int vi = lane + 64 * i;
+        if (vi < nvec) {
+            half8_t o;
+            half8_t av;
+            if (add) av = ld8(add + (size_t)row * ldadd + vi * 8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float t = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+                if (add) t += (float)av[e];
+                o[e] = to_half(t);
+            }
+            st8(dx + (size_t)row * lddx + vi * 8, o);
+        }
+    }
+}
+
+static int gn_geometry(int ctot, int* R, int* threads) {
+    int VC = ctot / 8;
+    if (VC > 1024) return 0;
+    int r = 256 / VC;
+    if (r < 1) r = 1;
+    *R = r;
+    *threads = ((VC * r + 63) / 64) * 64;
+    if (*threads < 64) *threads = 64;
+    return 1;
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+static int make_src(GnSrc* s, const void* a, const void* b, int lda, int ldb, int c1, int ctot, int hw) {
+    if (ctot <= 0 || ctot % 32 || ctot % 8 || c1 % 8 || c1 > ctot || c1 <= 0) return 0;
+    if (c1 < ctot && !b) return 0;
+    if (lda % 8 || (b && ldb % 8)) return 0;
+    s->a = (const half_t*)a; s->b = (const half_t*)b; s->lda = lda; s->ldb = ldb;
+    s->c1 = c1; s->ctot = ctot; s->hw = hw; s->cpg = ctot / 32;
+    return 1;
+}
+
+extern "C" int mc_gn_nchunk(int hw) {
+    int n = (hw + 63) / 64;
+    if (n < 1) n = 1;
+    if (n > 64) n = 64;
+    return n;
+}
+
+// workspace: float partial[frames * nchunk * 32 * 2]; output stats: float[frames*32*2] (mean, rstd)
+extern "C" int mc_groupnorm_stats_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot,
+                                      int frames, int hw, float eps, float* partial, float* stats,
+                                      void* stream) {
+    GnSrc s;
+    if (!make_src(&s, a, b, lda, ldb, c1, ctot, hw) || frames <= 0 || hw <= 0) return MC_ERR_SHAPE;
+    int R, threads;
+    if (!gn_geometry(ctot, &R, &threads)) return MC_ERR_UNSUPPORTED;
+    int nchunk = mc_gn_nchunk(hw);
+    size_t smem = (size_t)2 * R * ctot * sizeof(float);
+    MC_LAUNCH(gn_partial_kernel, dim3(nchunk, frames), dim3(threads), smem, (hipStream_t)stream, s, R, nchunk,
+              partial);
+    int n = frames * 32;
+    MC_LAUNCH(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+              (const float*)partial, stats, frames, nchunk, (float)hw * s.cpg, eps, 0);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot,
+                                      int frames, int hw, const float* stats, const float* gamma,
+                                      const float* beta, void* out, int ldo, int silu, void* stream) {
+    GnSrc s;
+    if (!make_src(&s, a, b, lda, ldb, c1, ctot, hw) || ldo % 8) return MC_ERR_SHAPE;
+    long total = (long)frames * hw * (ctot / 8);
+    int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    MC_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, stats, gamma, beta,
+              (half_t*)out, ldo, total, silu);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// workspace: partial as above + bstats float[frames*32*2]
+extern "C" int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot,
+                                    int frames, int hw, const void* dz, int lddz, const float* stats,
+                                    const float* gamma, const float* beta, int silu, float* partial,
+                                    float* bstats, void* dx, int lddx, int accumulate, void* stream) {
+    GnSrc s;
+    if (!make_src(&s, a, b, lda, ldb, c1, ctot, hw) || lddz % 8 || lddx % 8) return MC_ERR_SHAPE;
+    int R, threads;
+    if (!gn_geometry(ctot, &R, &threads)) return MC_ERR_UNSUPPORTED;
+    int nchunk = mc_gn_nchunk(hw);
+    size_t smem = (size_t)2 * R * ctot * sizeof(float);
+    MC_LAUNCH(gn_bwd_partial_kernel, dim3(nchunk, frames), dim3(threads), smem, (hipStream_t)stream, s,
+              (const half_t*)dz, lddz, stats, gamma, beta, silu, R, nchunk, partial);
+    int n = frames * 32;
+    MC_LAUNCH(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+              (const float*)partial, bstats, frames, nchunk, (float)hw * s.cpg, 0.f, 1);
+    long total = (long)frames * hw * (ctot / 8);
+    int blocks = (int)std::min<long>((total + 255) / 256, 4096);
+    MC_LAUNCH(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, (const half_t*)dz,
+              lddz, stats, (const float*)bstats, gamma, beta, silu, (half_t*)dx, lddx, total, accumulate);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_layernorm_fwd_f16(const void* x, int ldx, void* y, int ldy, const float* gamma,
+                                    const float* beta, const float* pe, int hw, int nframes_pe,
+                                    float* stats, int M, int C, float eps, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || C > 1536) return MC_ERR_SHAPE;
+    if (pe && (hw <= 0 || nframes_pe <= 0)) return MC_ERR_SHAPE;
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    int nv = (C / 8 + 63) / 64;
+    if (nv == 1)
+        MC_LAUNCH(ln_fwd_kernel<1>, grid, block, 0, s, (const half_t*)x, ldx, (half_t*)y, ldy, gamma, beta, pe,
+                  hw, nframes_pe, stats, M, C, eps);
+    else if (nv == 2)
+        MC_LAUNCH(ln_fwd_kernel<2>, grid, block, 0, s, (const half_t*)x, ldx, (half_t*)y, ldy, gamma, beta, pe,
+                  hw, nframes_pe, stats, M, C, eps);
+    else
+        MC_LAUNCH(ln_fwd_kernel<3>, grid, block, 0, s, (const half_t*)x, ldx, (half_t*)y, ldy, gamma, beta, pe,
+                  hw, nframes_pe, stats, M, C, eps);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_layernorm_bwd_f16(const void* dy, int lddy, const void* x, int ldx, const float* stats,
+                                    const float* gamma, const void* add, int ldadd, void* dx, int lddx,
+                                    int M, int C, void* stream) {
+    if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || lddy % 8 || lddx % 8 || C > 1536) return MC_ERR_SHAPE;
+    if (add && ldadd % 8) return MC_ERR_SHAPE;
+    dim3 grid((M + 3) / 4), block(256);
+    hipStream_t s = (hipStream_t)stream;
+    int nv = (C / 8 + 63) / 64;
+    if (nv == 1)
+        MC_LAUNCH(ln_bwd_kernel<1>, grid, block, 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx, stats,
+                  gamma, (const half_t*)add, ldadd, (half_t*)dx, lddx, M, C);
+    else if (nv == 2)
+        MC_LAUNCH(ln_bwd_kernel<2>, grid, block, 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx, stats,
+                  gamma, (const half_t*)add, ldadd, (half_t*)dx, lddx, M, C);
+    else
+        MC_LAUNCH(ln_bwd_kernel<3>, grid, block, 0, s, (const half_t*)dy, lddy, (const half_t*)x, ldx, stats,
+                  gamma, (const half_t*)add, ldadd, (half_t*)dx, lddx, M, C);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}

@@ -1,0 +1,508 @@
+// Temporal self-attention of the AnimateDiff motion modules and the MotionClone
+// guidance read-out on it.
+// Reference: motion_module.py:274-345 (attention over the F frames of one spatial
+// position), motionclone_functions.py:260-283 (P = softmax(scale q k^T)), :79
+// (top-1 value/index), :85-100 (gather + MSE), :236 (gradient).
+//
+// Layout: activations stay in token order [(b f) (h w), C]; the reference's
+// "(b f) d c -> (b d) f c" rearranges are index math here: the sequence of unit
+// (b, p, head) is rows {(b*F + f)*HW + p} at column offset head*d.
+// One wave per unit; the F x F score tile lives in MFMA accumulators
+// (v_mfma_f32_16x16x16_f16, NT = ceil(F/16) tiles per side).  The transposed score
+// tile S^T = K Q^T is computed so that softmax statistics are per-lane scalars
+// (query = lane & 15) and P^T in accumulator layout is directly the B operand of
+// O^T = V^T P^T - no cross-lane data movement for P.
+// The backward kernel fuses: recompute P, the guidance-loss seed
+// dP[q, idx[q]] += coef * (P[q, idx[q]] - ref[q]), softmax backward, and the three
+// operand gradients; both tile orientations are produced by swapping MFMA operands.
+#include "mc_common.hpp"
+
+namespace mc {
+
+struct TParams {
+    const half_t* q;
+    const half_t* k;
+    const half_t* v;
+    int ld;       // row stride of q/k/v (elements)
+    int B, F, HW, heads, d;
+    float scale;
+};
+
+struct TUnit {
+    int b, p, h;
+    bool live;
+};
+
+__device__ __forceinline__ TUnit t_unit(const TParams& P) {
+    int wave = threadIdx.x >> 6;
+    long u = (long)blockIdx.x * (blockDim.x >> 6) + wave;
+    TUnit r;
+    long units = (long)P.B * P.HW * P.heads;
+    r.live = u < units;
+    if (!r.live) u = 0;
+    r.h = (int)(u % P.heads);
+    long bp = u / P.heads;
+    r.p = (int)(bp % P.HW);
+    r.b = (int)(bp / P.HW);
+    return r;
+}
+
+__device__ __forceinline__ size_t t_row(const TParams& P, const TUnit& u, int f) {
+    return ((size_t)u.b * P.F + f) * P.HW + u.p;
+}
+
+// row operand: X[f = 16*t + (lane&15)][16*ks + 4*(lane>>4) .. +4]
+__device__ __forceinline__ half4_t t_row_frag(const half_t* x, int ld, const TParams& P, const TUnit& u, int t,
+                                              int ks, int lane) {
+    int f = 16 * t + (lane & 15);
+    int c = 16 * ks + 4 * (lane >> 4);
+    if (f < P.F && c < P.d) return ld4(x + t_row(P, u, f) * ld + u.h * P.d + c);
+    return zero4();
+}
+// column operand: X^T[c = 16*dt + (lane&15)][f = 16*t + 4*(lane>>4) + j]
+__device__ __forceinline__ half4_t t_col_frag(const half_t* x, int ld, const TParams& P, const TUnit& u, int t,
+                                              int dt, int lane) {
+    half4_t r;
+    int c = 16 * dt + (lane & 15);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        int f = 16 * t + 4 * (lane >> 4) + j;
+        r[j] = (f < P.F && c < P.d) ? x[t_row(P, u, f) * ld + u.h * P.d + c] : (half_t)0.f;
+    }
+    return r;
+}
+
+__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups sharing lane&15
+    v = fmaxf(v, shfl_xor(v, 16));
+    return fmaxf(v, shfl_xor(v, 32));
+}
+__device__ __forceinline__ float group_sum(float v) {
+    v += shfl_xor(v, 16);
+    return v + shfl_xor(v, 32);
+}
+
+// Scores of query tile tq against all key tiles, transposed orientation:
+// st[tk][i] = scale * S[q = 16tq + (lane&15)][kv = 16tk + 4g + i]; invalid kv -> -inf
+template <int NT, int DT>
+__device__ __forceinline__ void t_scores_T(const TParams& P, const TUnit& u, int tq, int lane, f32x4 (&st)[NT]) {
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk) st[tk] = fzero4();
+#pragma unroll
+    for (int ks = 0; ks < DT; ++ks) {
+        half4_t qf = t_row_frag(P.q, P.ld, P, u, tq, ks, lane);
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {
+            half4_t kf = t_row_frag(P.k, P.ld, P, u, tk, ks, lane);
+            st[tk] = mfma16(kf, qf, st[tk]);
+        }
+    }
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int kv = 16 * tk + 4 * (lane >> 4) + i;
+            st[tk][i] = kv < P.F ? st[tk][i] * P.scale : -INFINITY;
+        }
+}
+
+// softmax over kv for the lane's query column; returns (max, sum) and leaves exp(s - m) in st
+template <int NT>
+__device__ __forceinline__ void t_softmax_T(f32x4 (&st)[NT], float& m, float& l) {
+    m = -INFINITY;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) m = fmaxf(m, st[tk][i]);
+    m = group_max(m);
+    l = 0.f;
+#pragma unroll
+    for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float e = expf(st[tk][i] - m);
+            st[tk][i] = e;
+            l += e;
+        }
+    l = group_sum(l);
+}
+
+// ---- forward --------------------------------------------------------------------------------
+// mode 0: write attention output o; mode 1: write top-1 (value fp16, index u8) of P per query;
+// mode 2: write the per-query squared error (P[q, idx[q]] - ref[q])^2 summed per unit.
+template <int NT, int DT>
+__global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, int ldo, int mode,
+                                                         half_t* top_val, uint8_t* top_idx,
+                                                         const uint8_t* ref_idx, const float* ref_val,
+                                                         float* unit_loss) {
+    const int lane = threadIdx.x & 63;
+    TUnit u = t_unit(P);
+    if (!u.live) return;  // whole wave
+    const long unit = ((long)u.b * P.HW + u.p) * P.heads + u.h;
+    float loss_acc = 0.f;
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+        f32x4 st[NT];
+        t_scores_T<NT, DT>(P, u, tq, lane, st);
+        const int qf = 16 * tq + (lane & 15);
+        if (mode == 1) {
+            // arg-max over raw scores (lowest index wins ties), value = 1 / sum exp(s - max)
+            float best = -INFINITY;
+            int bi = 0;
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    int kv = 16 * tk + 4 * (lane >> 4) + i;
+                    if (st[tk][i] > best) {
+                        best = st[tk][i];
+                        bi = kv;
+                    }
+                }
+#pragma unroll
+            for (int msk = 16; msk <= 32; msk <<= 1) {
+                float ob = shfl_xor(best, msk);
+                int oi = shfl_xor(bi, msk);
+                if (ob > best || (ob == best && oi < bi)) {
+                    best = ob;
+                    bi = oi;
+                }
+            }
+            float m, l;
+            t_softmax_T<NT>(st, m, l);
+            if (lane < 16 && qf < P.F) {
+                top_val[unit * P.F + qf] = (half_t)(1.0f / l);
+                top_idx[unit * P.F + qf] = (uint8_t)bi;
+            }
+            continue;
+        }
+        float m, l;
+        t_softmax_T<NT>(st, m, l);
+        const float inv = 1.0f / l;
+        if (mode == 2) {
+            int idx = qf < P.F ? (int)ref_idx[unit * P.F + qf] : 0;
+            float pv = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (16 * tk + 4 * (lane >> 4) + i == idx) pv = st[tk][i] * inv;
+            pv = group_sum(pv);
+            if (lane < 16 && qf < P.F) {
+                float dlt = pv - ref_val[unit * P.F + qf];
+                loss_acc += dlt * dlt;
+            }
+            continue;
+        }
+        // O^T[dt] = sum_tk V^T[dt][tk] * P^T[tk]
+        half4_t pf[NT];
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) pf[tk][i] = (half_t)(st[tk][i] * inv);
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            f32x4 acc = fzero4();
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk) {
+                half4_t vf = t_col_frag(P.v, P.ld, P, u, tk, dt, lane);
+                acc = mfma16(vf, pf[tk], acc);
+            }
+            int c = 16 * dt + 4 * (lane >> 4);
+            if (qf < P.F && c < P.d) {
+                half4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = to_half(acc[i]);
+                st4(o + t_row(P, u, qf) * ldo + u.h * P.d + c, ov);
+            }
+        }
+    }
+    if (mode == 2) {
+        loss_acc = wave_sum(loss_acc);
+        if (lane == 0) unit_loss[unit] = loss_acc;
+    }
+}
+
+// ---- backward -------------------------------------------------------------------------------
+// inputs: q,k,v (P), dO (may be null), guidance seed (ref_idx/ref_val may be null, coef)
+// outputs: dq, dk, dv with row stride ldg (same token layout)
+template <int NT, int DT>
+__global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t* dO, int lddo, half_t* dq,
+                                                         half_t* dk, half_t* dv, int ldg,
+                                                         const uint8_t* ref_idx, const float* ref_val,
+                                                         float seed_coef) {
+    const int lane = threadIdx.x & 63;
+    const int g = lane >> 4, c15 = lane & 15;
+    TUnit u = t_unit(P);
+    if (!u.live) return;
+    const long unit = ((long)u.b * P.HW + u.p) * P.heads + u.h;
+
+    // S (q rows), S^T (kv rows), dP, dP^T accumulated over the head dimension
+    f32x4 s[NT][NT], sT[NT][NT], dp[NT][NT], dpT[NT][NT];  // [tq][tk]
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+        for (int b = 0; b < NT; ++b) s[a][b] = sT[a][b] = dp[a][b] = dpT[a][b] = fzero4();
+#pragma unroll
+    for (int ks = 0; ks < DT; ++ks) {
+        half4_t qf[NT], kf[NT], vf[NT], of[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            qf[t] = t_row_frag(P.q, P.ld, P, u, t, ks, lane);
+            kf[t] = t_row_frag(P.k, P.ld, P, u, t, ks, lane);
+            if (dO) {
+                vf[t] = t_row_frag(P.v, P.ld, P, u, t, ks, lane);
+                of[t] = t_row_frag(dO, lddo, P, u, t, ks, lane);
+            }
+        }
+#pragma unroll
+        for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk) {
+                s[tq][tk] = mfma16(qf[tq], kf[tk], s[tq][tk]);    // [q = 4g+i][kv = c15]
+                sT[tq][tk] = mfma16(kf[tk], qf[tq], sT[tq][tk]);  // [kv = 4g+i][q = c15]
+                if (dO) {
+                    dp[tq][tk] = mfma16(of[tq], vf[tk], dp[tq][tk]);
+                    dpT[tq][tk] = mfma16(vf[tk], of[tq], dpT[tq][tk]);
+                }
+            }
+    }
+
+    // per-query statistics in the transposed orientation (query = 16tq + c15)
+    float mq[NT], lq[NT], Dq[NT];
+    int idxq[NT];
+    float refq[NT];
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+        const int qv = 16 * tq + c15;
+        idxq[tq] = (ref_idx && qv < P.F) ? (int)ref_idx[unit * P.F + qv] : -1;
+        refq[tq] = (ref_idx && qv < P.F) ? ref_val[unit * P.F + qv] : 0.f;
+        float m = -INFINITY;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int kv = 16 * tk + 4 * g + i;
+                sT[tq][tk][i] = kv < P.F ? sT[tq][tk][i] * P.scale : -INFINITY;
+                m = fmaxf(m, sT[tq][tk][i]);
+            }
+        m = group_max(m);
+        float l = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) l += expf(sT[tq][tk][i] - m);
+        l = group_sum(l);
+        mq[tq] = m;
+        lq[tq] = l;
+        // P^T, total dP^T (attention path + guidance seed), D = sum_kv P * dP
+        float dsum = 0.f;
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                int kv = 16 * tk + 4 * g + i;
+                float pv = expf(sT[tq][tk][i] - m) / l;
+                float d = dpT[tq][tk][i];
+                if (kv == idxq[tq]) d += seed_coef * (pv - refq[tq]);
+                sT[tq][tk][i] = pv;
+                dpT[tq][tk][i] = d;
+                dsum += pv * d;
+            }
+        Dq[tq] = group_sum(dsum);
+    }
+
+    // dS^T = P^T * (dP^T - D) (fp16 B operands); and the q-row orientation via lane broadcasts
+    half4_t dsT[NT][NT], ds[NT][NT], pr[NT][NT];
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                dsT[tq][tk][i] = (half_t)(sT[tq][tk][i] * (dpT[tq][tk][i] - Dq[tq]));
+        // rows q = 16tq + 4g + i: fetch (m, l, D, idx, ref) from the lane whose column is that query
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int src = 4 * g + i;
+            float m = shfl(mq[tq], src), l = shfl(lq[tq], src), D = shfl(Dq[tq], src);
+            int idx = shfl(idxq[tq], src);
+            float rf = shfl(refq[tq], src);
+            const bool qok = 16 * tq + src < P.F;
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk) {
+                int kv = 16 * tk + c15;
+                float pv = 0.f, d = 0.f;
+                if (qok && kv < P.F) {
+                    pv = expf(s[tq][tk][i] * P.scale - m) / l;
+                    d = dp[tq][tk][i];
+                    if (kv == idx) d += seed_coef * (pv - rf);
+                }
+                pr[tq][tk][i] = (half_t)pv;
+                ds[tq][tk][i] = (half_t)(pv * (d - D));
+            }
+        }
+    }
+
+    // operand gradients, one 16-wide slice of the head dimension at a time
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+        const int c = 16 * dt + 4 * g;
+        half4_t kc[NT], qc[NT], oc[NT];
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            kc[t] = t_col_frag(P.k, P.ld, P, u, t, dt, lane);
+            qc[t] = t_col_frag(P.q, P.ld, P, u, t, dt, lane);
+            if (dO) oc[t] = t_col_frag(dO, lddo, P, u, t, dt, lane);
+        }
+#pragma unroll
+        for (int t = 0; t < NT; ++t) {
+            // dQ^T[d][q] = sum_kv K^T[d][kv] dS^T[kv][q]
+            f32x4 aq = fzero4(), ak = fzero4(), av = fzero4();
+#pragma unroll
+            for (int t2 = 0; t2 < NT; ++t2) {
+                aq = mfma16(kc[t2], dsT[t][t2], aq);
+                ak = mfma16(qc[t2], ds[t2][t], ak);       // dK^T[d][kv] = sum_q Q^T[d][q] dS[q][kv]
+                if (dO) av = mfma16(oc[t2], pr[t2][t], av);  // dV^T[d][kv] = sum_q dO^T[d][q] P[q][kv]
+            }
+            const int f = 16 * t + c15;
+            if (f < P.F && c < P.d) {
+                half4_t oq, ok, ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    oq[i] = to_half(aq[i] * P.scale);
+                    ok[i] = to_half(ak[i] * P.scale);
+                    ov[i] = to_half(av[i]);
+                }
+                size_t off = t_row(P, u, f) * ldg + u.h * P.d + c;
+                st4(dq + off, oq);
+                st4(dk + off, ok);
+                st4(dv + off, ov);
+            }
+        }
+    }
+}
+
+__global__ void reduce_sum_kernel(const float* in, long n, float scale, float* out) {
+    __shared__ float red[4];
+    float acc = 0.f;
+    for (long i = threadIdx.x; i < n; i += blockDim.x) acc += in[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
+}
+
+template <int NT, int DT>
+static void t_launch_fwd(const TParams& P, half_t* o, int ldo, int mode, half_t* tv, uint8_t* ti,
+                         const uint8_t* ri, const float* rv, float* ul, hipStream_t s) {
+    long units = (long)P.B * P.HW * P.heads;
+    MC_LAUNCH((tattn_fwd_kernel<NT, DT>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, o, ldo, mode, tv,
+              ti, ri, rv, ul);
+}
+template <int NT, int DT>
+static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* dq, half_t* dk, half_t* dv,
+                         int ldg, const uint8_t* ri, const float* rv, float coef, hipStream_t s) {
+    long units = (long)P.B * P.HW * P.heads;
+    MC_LAUNCH((tattn_bwd_kernel<NT, DT>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo, dq, dk,
+              dv, ldg, ri, rv, coef);
+}
+
+#define MC_T_DISPATCH(CALL)                                                     \
+    switch (nt * 16 + dt) {                                                     \
+        case 1 * 16 + 1: CALL(1, 1); break;                                     \
+        case 1 * 16 + 2: CALL(1, 2); break;                                     \
+        case 1 * 16 + 3: CALL(1, 3); break;                                     \
+        case 1 * 16 + 5: CALL(1, 5); break;                                     \
+        case 1 * 16 + 10: CALL(1, 10); break;                                   \
+        case 2 * 16 + 1: CALL(2, 1); break;                                     \
+        case 2 * 16 + 2: CALL(2, 2); break;                                     \
+        case 2 * 16 + 3: CALL(2, 3); break;                                     \
+        case 2 * 16 + 5: CALL(2, 5); break;                                     \
+        case 2 * 16 + 10: CALL(2, 10); break;                                   \
+        default: return MC_ERR_UNSUPPORTED;                                     \
+    }
+
+static int t_check(const TParams& P) {
+    if (P.B <= 0 || P.F <= 0 || P.HW <= 0 || P.heads <= 0 || P.d <= 0) return 0;
+    if (P.d % 4 || P.ld % 4 || P.F > 32) return 0;
+    return 1;
+}
+
+}  // namespace mc
+
+using namespace mc;
+
+static TParams t_params(const void* q, const void* k, const void* v, int ld, int B, int F, int HW, int heads,
+                        int d, float scale) {
+    TParams P;
+    P.q = (const half_t*)q; P.k = (const half_t*)k; P.v = (const half_t*)v;
+    P.ld = ld; P.B = B; P.F = F; P.HW = HW; P.heads = heads; P.d = d; P.scale = scale;
+    return P;
+}
+
+extern "C" int mc_tattn_fwd_f16(const void* q, const void* k, const void* v, int ld, void* o, int ldo, int B,
+                                int F, int HW, int heads, int d, float scale, void* stream) {
+    TParams P = t_params(q, k, v, ld, B, F, HW, heads, d, scale);
+    if (!t_check(P) || ldo % 4) return MC_ERR_SHAPE;
+    int nt = (F + 15) / 16, dt = (d + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(NT_, DT_) t_launch_fwd<NT_, DT_>(P, (half_t*)o, ldo, 0, nullptr, nullptr, nullptr, nullptr, nullptr, s)
+    MC_T_DISPATCH(CALL)
+#undef CALL
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// motion representation: top_val fp16 [B*HW, heads, F], top_idx u8 [B*HW, heads, F]
+extern "C" int mc_tattn_top1_f16(const void* q, const void* k, int ld, void* top_val, void* top_idx, int B,
+                                 int F, int HW, int heads, int d, float scale, void* stream) {
+    TParams P = t_params(q, k, k, ld, B, F, HW, heads, d, scale);
+    if (!t_check(P)) return MC_ERR_SHAPE;
+    int nt = (F + 15) / 16, dt = (d + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(NT_, DT_) \
+    t_launch_fwd<NT_, DT_>(P, nullptr, 0, 1, (half_t*)top_val, (uint8_t*)top_idx, nullptr, nullptr, nullptr, s)
+    MC_T_DISPATCH(CALL)
+#undef CALL
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// loss[0] = mean over (unit, frame) of (P[q, idx] - ref)^2; workspace unit_loss float[B*HW*heads]
+extern "C" int mc_tattn_loss_f16(const void* q, const void* k, int ld, const void* ref_idx,
+                                 const float* ref_val, float* unit_loss, float* loss, int B, int F, int HW,
+                                 int heads, int d, float scale, void* stream) {
+    TParams P = t_params(q, k, k, ld, B, F, HW, heads, d, scale);
+    if (!t_check(P)) return MC_ERR_SHAPE;
+    int nt = (F + 15) / 16, dt = (d + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(NT_, DT_) \
+    t_launch_fwd<NT_, DT_>(P, nullptr, 0, 2, nullptr, nullptr, (const uint8_t*)ref_idx, ref_val, unit_loss, s)
+    MC_T_DISPATCH(CALL)
+#undef CALL
+    long units = (long)B * HW * heads;
+    MC_LAUNCH(reduce_sum_kernel, dim3(1), dim3(256), 0, s, (const float*)unit_loss, units,
+              1.0f / (float)(units * F), loss);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_tattn_bwd_f16(const void* q, const void* k, const void* v, int ld, const void* dO, int lddo,
+                                void* dq, void* dk, void* dv, int ldg, const void* ref_idx,
+                                const float* ref_val, float seed_coef, int B, int F, int HW, int heads, int d,
+                                float scale, void* stream) {
+    TParams P = t_params(q, k, v, ld, B, F, HW, heads, d, scale);
+    if (!t_check(P) || ldg % 4 || (dO && lddo % 4)) return MC_ERR_SHAPE;
+    if (!dO && !ref_idx) return MC_ERR_SHAPE;
+    int nt = (F + 15) / 16, dt = (d + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(NT_, DT_)                                                                                        \
+    t_launch_bwd<NT_, DT_>(P, (const half_t*)dO, lddo, (half_t*)dq, (half_t*)dk, (half_t*)dv, ldg,          \
+                           (const uint8_t*)ref_idx, ref_val, seed_coef, s)
+    MC_T_DISPATCH(CALL)
+#undef CALL
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_reduce_sum_f32(const float* in, long n, float scale, float* out, void* stream) {
+    if (n <= 0) return MC_ERR_SHAPE;
+    MC_LAUNCH(reduce_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, in, n, scale, out);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}

@@ -1,0 +1,93 @@
+"""ctypes binding of the C ABI in include/mc_kernels.h.
+
+The product path opens exactly one library: csrc/libmotionclone_hip.so, built by hipcc for gfx950
+(`python -m motionclone_amd.build` or `__graft_entry__.build()`).  If it is missing the import of any
+op fails loudly - there is no eager / CPU fallback.
+
+`use_library_for_tests()` lets the CPU-only test-suite point the same wrappers at the host simulator
+build of the kernels (tests/hipemu); it is never called from the package itself.
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libmotionclone_hip.so")
+
+c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
+P, I, L, F = c_void_p, c_int, c_long, c_float
+
+# name -> argument ctypes, in the order of include/mc_kernels.h
+SIGNATURES = {
+    "mc_version": [],
+    "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
+    "mc_gn_nchunk": [I],
+    "mc_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, F, P, P, P],
+    "mc_groupnorm_apply_f16": [P, P, I, I, I, I, I, I, P, P, P, P, I, I, P],
+    "mc_groupnorm_bwd_f16": [P, P, I, I, I, I, I, I, P, I, P, P, P, I, P, P, P, I, I, P],
+    "mc_layernorm_fwd_f16": [P, I, P, I, P, P, P, I, I, P, I, I, F, P],
+    "mc_layernorm_bwd_f16": [P, I, P, I, P, P, P, I, P, I, I, I, P],
+    "mc_attn_fwd_f16": [P, P, P, I, I, I, P, I, P, I, I, I, I, I, I, F, P],
+    "mc_attn_bwd_f16": [P, P, P, I, I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, I, I, I, I, F, P],
+    "mc_tattn_fwd_f16": [P, P, P, I, P, I, I, I, I, I, I, F, P],
+    "mc_tattn_top1_f16": [P, P, I, P, P, I, I, I, I, I, F, P],
+    "mc_tattn_loss_f16": [P, P, I, P, P, P, P, I, I, I, I, I, F, P],
+    "mc_tattn_bwd_f16": [P, P, P, I, P, I, P, P, P, I, P, P, F, I, I, I, I, I, F, P],
+    "mc_reduce_sum_f32": [P, L, F, P, P],
+    "mc_geglu_fwd_f16": [P, I, P, I, I, I, P],
+    "mc_geglu_bwd_f16": [P, I, P, I, P, I, I, I, P],
+    "mc_add_f16": [P, I, P, I, P, I, I, I, F, F, P],
+    "mc_sumpool2_f16": [P, I, P, I, I, I, I, I, I, P],
+    "mc_latent_to_cl_f16": [P, P, I, I, I, I, I, P],
+    "mc_cl_to_latent_f16": [P, I, P, I, F, I, I, I, I, P],
+    "mc_timestep_embed_f16": [P, P, I, I, P],
+    "mc_silu_f16": [P, P, L, P],
+    "mc_cfg_ddim_step_f16": [P, P, I, P, P, P, P, F, F, F, F, F, F, I, I, I, P],
+}
+
+ERRORS = {-1: "bad shape / stride / alignment", -2: "unsupported size", -3: "kernel launch failed"}
+
+_lib = None
+_is_emulated = False
+
+
+class KernelLibraryMissing(RuntimeError):
+    pass
+
+
+def _bind(path):
+    lib = ctypes.CDLL(path)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    return lib
+
+
+def load():
+    """Return the bound gfx950 library; raise if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(HIP_LIB_PATH):
+            raise KernelLibraryMissing(
+                "%s not found: build it with `python -m motionclone_amd.build` (hipcc, gfx950). "
+                "There is no fallback path." % HIP_LIB_PATH)
+        _lib = _bind(HIP_LIB_PATH)
+    return _lib
+
+
+def use_library_for_tests(path):
+    """TEST HOOK: route the wrappers to the host-simulator build of the kernel sources."""
+    global _lib, _is_emulated
+    _lib = _bind(path)
+    _is_emulated = True
+    return _lib
+
+
+def is_emulated():
+    return _is_emulated
+
+
+def call(name, *args):
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (rc=%d)" % (name, ERRORS.get(rc, "unknown"), rc))

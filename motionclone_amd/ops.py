@@ -1,0 +1,281 @@
+"""Thin tensor-level wrappers over the C ABI (include/mc_kernels.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every arithmetic step is a call
+into libmotionclone_hip.so.  Activations are fp16 token matrices [tokens, C] (token order
+(b, f, y, x)); a strided column window of a wider matrix is passed as a view (stride(1) == 1).
+"""
+import torch
+
+from . import lib
+
+DENSE, CONV_S1, CONV_S2, CONV_UP, TCONV_S2 = 0, 1, 2, 3, 4
+
+
+def _stream(t):
+    if t.is_cuda:
+        return torch.cuda.current_stream(t.device).cuda_stream
+    if not lib.is_emulated():
+        raise RuntimeError("motionclone_amd kernels run on an MI355X; got a CPU tensor and no GPU library "
+                           "(there is no CPU fallback)")
+    return 0
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t):
+    if t is None:
+        return 0
+    assert t.dim() == 2 and t.stride(1) == 1, "expected a row-major 2-D (possibly column-windowed) matrix"
+    return t.stride(0)
+
+
+def _f16(t):
+    assert t.dtype == torch.float16, t.dtype
+    return t
+
+
+def _f32(t):
+    assert t is None or (t.dtype == torch.float32 and t.is_contiguous())
+    return t
+
+
+def empty(shape, like, dtype=torch.float16):
+    return torch.empty(shape, dtype=dtype, device=like.device)
+
+
+# ---- GEMM family ---------------------------------------------------------------------------------
+def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
+         rows_per_batch=0, tile=0, m_out=None):
+    """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
+
+    geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes."""
+    _f16(a), _f16(w)
+    N, K = w.shape
+    c1 = a.shape[1]
+    ctot = c1 + (a2.shape[1] if a2 is not None else 0)
+    if mode == DENSE:
+        M = a.shape[0]
+        assert ctot == K, (ctot, K)
+        Hs = Ws = Ho = Wo = 0
+    else:
+        Hs, Ws, Ho, Wo = geom
+        M = m_out
+        assert K == 9 * ctot, (K, ctot)
+    if out is None:
+        out = empty((M, N), a)
+    assert out.shape[0] == M and out.shape[1] == N
+    if bias is not None:
+        _f32(bias)
+        assert bias.shape[-1] == N
+    lib.call("mc_gemm_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a), _ld(a2),
+             _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha), tile,
+             _stream(a))
+    return out
+
+
+# ---- GroupNorm -------------------------------------------------------------------------------------
+def gn_stats(x, x2, frames, hw, eps):
+    c1 = x.shape[1]
+    ctot = c1 + (x2.shape[1] if x2 is not None else 0)
+    nchunk = lib.load().mc_gn_nchunk(hw)
+    partial = empty((frames * nchunk * 64,), x, torch.float32)
+    stats = empty((frames, 32, 2), x, torch.float32)
+    lib.call("mc_groupnorm_stats_f16", _p(x), _p(x2), _ld(x), _ld(x2), c1, ctot, frames, hw, float(eps),
+             _p(partial), _p(stats), _stream(x))
+    return stats
+
+
+def gn_apply(x, x2, stats, gamma, beta, silu, frames, hw, out=None):
+    c1 = x.shape[1]
+    ctot = c1 + (x2.shape[1] if x2 is not None else 0)
+    if out is None:
+        out = empty((frames * hw, ctot), x)
+    lib.call("mc_groupnorm_apply_f16", _p(x), _p(x2), _ld(x), _ld(x2), c1, ctot, frames, hw, _p(stats),
+             _p(_f32(gamma)), _p(_f32(beta)), _p(out), _ld(out), int(silu), _stream(x))
+    return out
+
+
+def gn_bwd(x, x2, dz, stats, gamma, beta, silu, frames, hw, out=None, accumulate=False):
+    c1 = x.shape[1]
+    ctot = c1 + (x2.shape[1] if x2 is not None else 0)
+    nchunk = lib.load().mc_gn_nchunk(hw)
+    partial = empty((frames * nchunk * 64,), x, torch.float32)
+    bstats = empty((frames * 64,), x, torch.float32)
+    if out is None:
+        assert not accumulate
+        out = empty((frames * hw, ctot), x)
+    lib.call("mc_groupnorm_bwd_f16", _p(x), _p(x2), _ld(x), _ld(x2), c1, ctot, frames, hw, _p(dz), _ld(dz),
+             _p(stats), _p(_f32(gamma)), _p(_f32(beta)), int(silu), _p(partial), _p(bstats), _p(out), _ld(out),
+             int(accumulate), _stream(x))
+    return out
+
+
+# ---- LayerNorm -------------------------------------------------------------------------------------
+def layernorm_fwd(x, gamma, beta, eps=1e-5, pe=None, hw=0, save_stats=True, out=None):
+    M, C = x.shape
+    if out is None:
+        out = empty((M, C), x)
+    stats = empty((M, 2), x, torch.float32) if save_stats else None
+    nfr = pe.shape[0] if pe is not None else 0
+    lib.call("mc_layernorm_fwd_f16", _p(x), _ld(x), _p(out), _ld(out), _p(_f32(gamma)), _p(_f32(beta)),
+             _p(_f32(pe)), hw, nfr, _p(stats), M, C, float(eps), _stream(x))
+    return out, stats
+
+
+def layernorm_bwd(dy, x, stats, gamma, add=None, out=None):
+    M, C = x.shape
+    if out is None:
+        out = empty((M, C), x)
+    lib.call("mc_layernorm_bwd_f16", _p(dy), _ld(dy), _p(x), _ld(x), _p(stats), _p(_f32(gamma)), _p(add),
+             _ld(add), _p(out), _ld(out), M, C, _stream(x))
+    return out
+
+
+# ---- spatial / cross attention ----------------------------------------------------------------------
+def attn_fwd(q, k, v, Nq, Nk, heads, d, nbatch, kv_bdiv=1, scale=None, need_lse=True, out=None):
+    scale = d ** -0.5 if scale is None else scale
+    if out is None:
+        out = empty((q.shape[0], heads * d), q)
+    lse = empty((nbatch, heads, Nq), q, torch.float32) if need_lse else None
+    lib.call("mc_attn_fwd_f16", _p(q), _p(k), _p(v), _ld(q), _ld(k), _ld(v), _p(out), _ld(out), _p(lse), Nq, Nk,
+             heads, d, nbatch, kv_bdiv, float(scale), _stream(q))
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nbatch, kv_bdiv=1, scale=None, dq=None, dk=None, dv=None,
+             need_dkv=True):
+    scale = d ** -0.5 if scale is None else scale
+    dbuf = empty((nbatch * heads * Nq,), q, torch.float32)
+    if dq is None:
+        dq = empty((q.shape[0], heads * d), q)
+    if need_dkv:
+        if dk is None:
+            dk = empty((k.shape[0], heads * d), q)
+        if dv is None:
+            dv = empty((v.shape[0], heads * d), q)
+    lib.call("mc_attn_bwd_f16", _p(q), _p(k), _p(v), _ld(q), _ld(k), _ld(v), _p(o), _ld(o), _p(do), _ld(do),
+             _p(lse), _p(dbuf), _p(dq), _ld(dq), _p(dk) if need_dkv else None, _ld(dk) if need_dkv else 0,
+             _p(dv) if need_dkv else None, _ld(dv) if need_dkv else 0, Nq, Nk, heads, d, nbatch, kv_bdiv,
+             float(scale), _stream(q))
+    return dq, dk, dv
+
+
+# ---- temporal attention + guidance --------------------------------------------------------------------
+def tattn_fwd(q, k, v, B, F, HW, heads, d, scale=None, out=None):
+    scale = d ** -0.5 if scale is None else scale
+    if out is None:
+        out = empty((q.shape[0], heads * d), q)
+    assert _ld(q) == _ld(k) == _ld(v)
+    lib.call("mc_tattn_fwd_f16", _p(q), _p(k), _p(v), _ld(q), _p(out), _ld(out), B, F, HW, heads, d,
+             float(scale), _stream(q))
+    return out
+
+
+def tattn_top1(q, k, B, F, HW, heads, d, scale=None):
+    """-> (values fp16 [B*HW, heads, F, 1], indices uint8 [B*HW, heads, F, 1]) as stored by the reference."""
+    scale = d ** -0.5 if scale is None else scale
+    assert _ld(q) == _ld(k)
+    val = empty((B * HW, heads, F, 1), q)
+    idx = empty((B * HW, heads, F, 1), q, torch.uint8)
+    lib.call("mc_tattn_top1_f16", _p(q), _p(k), _ld(q), _p(val), _p(idx), B, F, HW, heads, d, float(scale),
+             _stream(q))
+    return val, idx
+
+
+def tattn_loss(q, k, ref_idx, ref_val, B, F, HW, heads, d, scale=None):
+    scale = d ** -0.5 if scale is None else scale
+    assert ref_idx.dtype == torch.uint8 and ref_idx.is_contiguous()
+    _f32(ref_val)
+    ul = empty((B * HW * heads,), q, torch.float32)
+    loss = empty((1,), q, torch.float32)
+    lib.call("mc_tattn_loss_f16", _p(q), _p(k), _ld(q), _p(ref_idx), _p(ref_val), _p(ul), _p(loss), B, F, HW,
+             heads, d, float(scale), _stream(q))
+    return loss
+
+
+def tattn_bwd(q, k, v, do, dq, dk, dv, B, F, HW, heads, d, ref_idx=None, ref_val=None, seed_coef=0.0,
+              scale=None):
+    scale = d ** -0.5 if scale is None else scale
+    assert _ld(q) == _ld(k) == _ld(v) and _ld(dq) == _ld(dk) == _ld(dv)
+    if ref_idx is not None:
+        assert ref_idx.dtype == torch.uint8 and ref_idx.is_contiguous()
+        _f32(ref_val)
+    lib.call("mc_tattn_bwd_f16", _p(q), _p(k), _p(v), _ld(q), _p(do), _ld(do), _p(dq), _p(dk), _p(dv), _ld(dq),
+             _p(ref_idx), _p(ref_val), float(seed_coef), B, F, HW, heads, d, float(scale), _stream(q))
+
+
+# ---- element-wise ------------------------------------------------------------------------------------
+def geglu_fwd(x, out=None):
+    M, D2 = x.shape
+    D = D2 // 2
+    if out is None:
+        out = empty((M, D), x)
+    lib.call("mc_geglu_fwd_f16", _p(x), _ld(x), _p(out), _ld(out), M, D, _stream(x))
+    return out
+
+
+def geglu_bwd(dout, x, out=None):
+    M, D2 = x.shape
+    if out is None:
+        out = empty((M, D2), x)
+    lib.call("mc_geglu_bwd_f16", _p(dout), _ld(dout), _p(x), _ld(x), _p(out), _ld(out), M, D2 // 2, _stream(x))
+    return out
+
+
+def add(a, b=None, out=None, sa=1.0, sb=1.0):
+    M, C = a.shape
+    if out is None:
+        out = empty((M, C), a)
+    lib.call("mc_add_f16", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C, float(sa), float(sb), _stream(a))
+    return out
+
+
+def sumpool2(x, frames, H, W, out=None, accumulate=False):
+    C = x.shape[1]
+    if out is None:
+        out = empty((frames * H * W, C), x)
+    lib.call("mc_sumpool2_f16", _p(x), _ld(x), _p(out), _ld(out), frames, H, W, C, int(accumulate), _stream(x))
+    return out
+
+
+def latent_to_cl(lat, cp=64):
+    B, CL, F, H, W = lat.shape
+    lat = lat.contiguous()
+    out = empty((B * F * H * W, cp), lat)
+    lib.call("mc_latent_to_cl_f16", _p(lat), _p(out), B, CL, F, H * W, cp, _stream(lat))
+    return out
+
+
+def cl_to_latent(x, B, CL, F, H, W, scale=1.0, f32=False):
+    out = empty((B, CL, F, H, W), x, torch.float32 if f32 else torch.float16)
+    lib.call("mc_cl_to_latent_f16", _p(x), _ld(x), _p(out), int(f32), float(scale), B, CL, F, H * W, _stream(x))
+    return out
+
+
+def timestep_embed(t, dim, like):
+    out = empty((t.shape[0], dim), like)
+    lib.call("mc_timestep_embed_f16", _p(_f32(t)), _p(out), t.shape[0], dim, _stream(like))
+    return out
+
+
+def silu(x):
+    out = torch.empty_like(x)
+    lib.call("mc_silu_f16", _p(x), _p(out), x.numel(), _stream(x))
+    return out
+
+
+def cfg_ddim_step(eps_c, eps_u, x, score, cfg, a_t, a_prev, score_coef, want_eps=False):
+    """x, score: [1, CL, F, H, W]; eps_*: channels-last token matrices (first CL columns)."""
+    _, CL, F, H, W = x.shape
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    eps_out = torch.empty_like(x) if want_eps else None
+    if score is not None:
+        score = _f32(score.contiguous())
+    assert _ld(eps_c) == _ld(eps_u)
+    lib.call("mc_cfg_ddim_step_f16", _p(eps_c), _p(eps_u), _ld(eps_c), _p(x), _p(score), _p(out), _p(eps_out),
+             float(cfg), float(a_t) ** 0.5, float(1.0 - a_t) ** 0.5, float(a_prev) ** 0.5,
+             float(1.0 - a_prev) ** 0.5, float(score_coef), CL, F, H * W, _stream(x))
+    return (out, eps_out) if want_eps else out

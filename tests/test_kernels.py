@@ -1,0 +1,339 @@
+"""Per-kernel numerics: every C-ABI entry point against a plain PyTorch fp32 reference of the same op.
+
+Each test runs twice: on the host simulator build of the kernel sources (CPU, here) and - marked
+`gpu` - on the real gfx950 library.  Tolerances are fp16-output tolerances against fp32 math.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as Fn
+
+from motionclone_amd import ops
+
+
+def big(dev):
+    return dev.type == "cuda"
+
+
+def rnd(shape, dev, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(torch.float16).to(dev)
+
+
+def close(a, b, atol, rtol, what=""):
+    a = a.float().cpu()
+    b = b.float().cpu()
+    err = (a - b).abs()
+    tol = atol + rtol * b.abs()
+    bad = (err > tol).float().mean().item()
+    assert torch.isfinite(a).all(), what + ": non-finite output"
+    assert bad == 0.0, "%s: %.4f%% elements off, max err %.4g (ref max %.3g)" % (
+        what, 100 * bad, err.max().item(), b.abs().max().item())
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,N,K,tile", [(200, 72, 128, 64), (300, 136, 192, 128), (77, 64, 64, 0)])
+def test_gemm_dense(backend, M, N, K, tile):
+    dev = backend
+    if big(dev):
+        M, N, K = M * 8 + 5, N * 4, K * 4
+    a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+    bias = torch.randn(2, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = rnd((M, N), dev, 4)
+    rpb = (M + 1) // 2
+    out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=rpb, alpha=0.5, tile=tile)
+    b_idx = (torch.arange(M, device=dev) // rpb)
+    ref = 0.5 * (a.float() @ w.float().t()) + bias[b_idx] + res.float()
+    close(out, ref, 2e-2, 5e-3, "gemm")
+    # asymmetric operands would expose a transposed C-write; also check no-epilogue path
+    out2 = ops.gemm(a, w, tile=tile)
+    close(out2, a.float() @ w.float().t(), 2e-2, 5e-3, "gemm plain")
+
+
+def test_gemm_concat_and_strided_out(backend):
+    dev = backend
+    M, C1, C2, N = 130, 64, 128, 96
+    a, a2, w = rnd((M, C1), dev, 1), rnd((M, C2), dev, 2), rnd((N, C1 + C2), dev, 3, 0.1)
+    wide = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
+    ops.gemm(a, w, a2=a2, out=wide[:, N:2 * N])
+    ref = torch.cat([a, a2], 1).float() @ w.float().t()
+    close(wide[:, N:2 * N], ref, 2e-2, 5e-3, "gemm concat")
+    assert wide[:, :N].abs().max() == 0 and wide[:, 2 * N:].abs().max() == 0
+
+
+def _conv_w_pack(w):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin] tap-major
+    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+
+
+def _to_cl(x):  # [NF, C, H, W] -> [NF*H*W, C]
+    return x.permute(0, 2, 3, 1).reshape(-1, x.shape[1]).contiguous()
+
+
+def _from_cl(x, NF, H, W):
+    return x.reshape(NF, H, W, -1).permute(0, 3, 1, 2)
+
+
+@pytest.mark.parametrize("mode", ["s1", "s2", "up", "concat"])
+def test_conv3x3(backend, mode):
+    dev = backend
+    NF, Cin, Cout, H, W = (3, 64, 72, 6, 10) if not big(dev) else (5, 192, 200, 24, 20)
+    x = rnd((NF, Cin, H, W), dev, 1)
+    w = rnd((Cout, Cin, 3, 3), dev, 2, 0.05)
+    bias = torch.randn(1, Cout, generator=torch.Generator().manual_seed(3)).to(dev)
+    xc = _to_cl(x)
+    wp = _conv_w_pack(w)
+    if mode == "s1":
+        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
+        ref = Fn.conv2d(x.float(), w.float(), bias[0], padding=1)
+        Ho, Wo = H, W
+    elif mode == "s2":
+        Ho, Wo = H // 2, W // 2
+        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_S2, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
+        ref = Fn.conv2d(x.float(), w.float(), bias[0], padding=1, stride=2)
+    elif mode == "up":
+        Ho, Wo = 2 * H, 2 * W
+        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_UP, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
+        ref = Fn.conv2d(Fn.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias[0], padding=1)
+    else:
+        x2 = rnd((NF, 128, H, W), dev, 5)
+        w = rnd((Cout, Cin + 128, 3, 3), dev, 6, 0.05)
+        out = ops.gemm(xc, _conv_w_pack(w), a2=_to_cl(x2), bias=bias, mode=ops.CONV_S1, geom=(H, W, H, W),
+                       m_out=NF * H * W)
+        ref = Fn.conv2d(torch.cat([x, x2], 1).float(), w.float(), bias[0], padding=1)
+        Ho, Wo = H, W
+    close(_from_cl(out, NF, Ho, Wo), ref, 3e-2, 5e-3, "conv " + mode)
+
+
+@pytest.mark.parametrize("stride", [1, 2])
+def test_conv3x3_dgrad(backend, stride):
+    """data-gradient of the 3x3 conv = the same kernel with re-packed weights (autograd is the reference)."""
+    dev = backend
+    NF, Cin, Cout, H, W = (2, 64, 64, 8, 6) if not big(dev) else (4, 128, 192, 16, 24)
+    x = rnd((NF, Cin, H, W), dev, 1).float().requires_grad_()
+    w = rnd((Cout, Cin, 3, 3), dev, 2, 0.05)
+    y = Fn.conv2d(x, w.float(), padding=1, stride=stride)
+    dy = rnd(tuple(y.shape), dev, 3)
+    (ref,) = torch.autograd.grad(y, x, dy.float())
+    Ho, Wo = y.shape[2:]
+    if stride == 1:
+        wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+        out = ops.gemm(_to_cl(dy), wd, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
+    else:
+        wd = w.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+        out = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(Ho, Wo, H, W), m_out=NF * H * W)
+    close(_from_cl(out, NF, H, W), ref, 3e-2, 5e-3, "conv dgrad s%d" % stride)
+
+
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("C1,C2,silu", [(64, 0, True), (320, 0, False), (64, 128, True), (960, 0, True)])
+def test_groupnorm_fwd_bwd(backend, C1, C2, silu):
+    dev = backend
+    NF, H, W = (3, 5, 7) if not big(dev) else (6, 32, 24)
+    C = C1 + C2
+    x = rnd((NF, C, H, W), dev, 1) + 0.5
+    gamma = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2))).to(dev)
+    beta = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(3))).to(dev)
+    xa = _to_cl(x[:, :C1])
+    xb = _to_cl(x[:, C1:]) if C2 else None
+    stats = ops.gn_stats(xa, xb, NF, H * W, 1e-5)
+    y = ops.gn_apply(xa, xb, stats, gamma, beta, silu, NF, H * W)
+    xr = x.float().requires_grad_()
+    ref = Fn.group_norm(xr, 32, gamma, beta, 1e-5)
+    if silu:
+        ref = Fn.silu(ref)
+    close(_from_cl(y, NF, H, W), ref, 1e-2, 5e-3, "gn fwd")
+    dz = rnd((NF, C, H, W), dev, 4)
+    (dref,) = torch.autograd.grad(ref, xr, dz.float())
+    dx = ops.gn_bwd(xa, xb, _to_cl(dz), stats, gamma, beta, silu, NF, H * W)
+    close(_from_cl(dx, NF, H, W), dref, 1e-2, 1e-2, "gn bwd")
+    # accumulate form
+    base = rnd((NF * H * W, C), dev, 5)
+    acc = base.clone()
+    ops.gn_bwd(xa, xb, _to_cl(dz), stats, gamma, beta, silu, NF, H * W, out=acc, accumulate=True)
+    close(acc, dx.float() + base.float(), 1e-2, 1e-2, "gn bwd accumulate")
+
+
+@pytest.mark.parametrize("C", [64, 320, 1280])
+def test_layernorm_fwd_bwd(backend, C):
+    dev = backend
+    F_, HW = 3, 5
+    M = 2 * F_ * HW + (0 if not big(dev) else 4096)
+    M -= M % (F_ * HW)
+    x = rnd((M, C), dev, 1) * 2 + 0.3
+    gamma = (1 + 0.1 * torch.randn(C, generator=torch.Generator().manual_seed(2))).to(dev)
+    beta = (0.1 * torch.randn(C, generator=torch.Generator().manual_seed(3))).to(dev)
+    pe = torch.randn(F_, C, generator=torch.Generator().manual_seed(4)).to(dev)
+    y, stats = ops.layernorm_fwd(x, gamma, beta, 1e-5, pe=pe, hw=HW)
+    xr = x.float().requires_grad_()
+    ref0 = Fn.layer_norm(xr, (C,), gamma, beta, 1e-5)
+    frame = (torch.arange(M, device=dev) // HW) % F_
+    close(y, ref0 + pe[frame], 1e-2, 5e-3, "ln fwd")
+    dy = rnd((M, C), dev, 5)
+    addv = rnd((M, C), dev, 6)
+    (dref,) = torch.autograd.grad(ref0, xr, dy.float())
+    dx = ops.layernorm_bwd(dy, x, stats, gamma, add=addv)
+    close(dx, dref + addv.float(), 1e-2, 1e-2, "ln bwd")
+
+
+# ---------------------------------------------------------------------------------------------------
+def _heads(t, nb, n, heads, d):  # [nb*n, heads*d] -> [nb, heads, n, d]
+    return t.float().reshape(nb, n, heads, d).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("d,Nq", [(16, 70), (40, 150), (80, 64), (160, 40)])
+def test_self_attention_fwd_bwd(backend, d, Nq):
+    dev = backend
+    heads, nb = 2, 2
+    if big(dev):
+        Nq, heads, nb = Nq * 9 + 3, 4, 3
+    C = heads * d
+    qkv = rnd((nb * Nq, 3 * C), dev, 1, 0.7)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o, lse = ops.attn_fwd(q, k, v, Nq, Nq, heads, d, nb)
+    Q, K, V = (_heads(t, nb, Nq, heads, d).requires_grad_() for t in (q, k, v))
+    S = (Q @ K.transpose(-1, -2)) * d ** -0.5
+    ref = S.softmax(-1) @ V
+    close(_heads(o, nb, Nq, heads, d), ref, 1e-2, 1e-2, "attn fwd")
+    close(lse, torch.logsumexp(S, -1), 2e-3, 1e-3, "attn lse")
+    do = rnd((nb * Nq, C), dev, 2)
+    gq, gk, gv = torch.autograd.grad(ref, (Q, K, V), _heads(do, nb, Nq, heads, d))
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_bwd(q, k, v, o, do, lse, Nq, Nq, heads, d, nb, dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+    close(_heads(dqkv[:, :C], nb, Nq, heads, d), gq, 1e-2, 2e-2, "attn dq")
+    close(_heads(dqkv[:, C:2 * C], nb, Nq, heads, d), gk, 1e-2, 2e-2, "attn dk")
+    close(_heads(dqkv[:, 2 * C:], nb, Nq, heads, d), gv, 1e-2, 2e-2, "attn dv")
+
+
+def test_cross_attention_fwd_bwd(backend):
+    dev = backend
+    heads, d, B, F_, N, Nk = 2, 40, 2, 3, 50, 77
+    if big(dev):
+        heads, d, N = 8, 40, 1024
+    C = heads * d
+    nb = B * F_
+    q = rnd((nb * N, C), dev, 1, 0.7)
+    kv = rnd((B * Nk, 2 * C), dev, 2, 0.7)
+    k, v = kv[:, :C], kv[:, C:]
+    o, lse = ops.attn_fwd(q, k, v, N, Nk, heads, d, nb, kv_bdiv=F_)
+    Q = _heads(q, nb, N, heads, d).requires_grad_()
+    K = _heads(k, B, Nk, heads, d).repeat_interleave(F_, 0)
+    V = _heads(v, B, Nk, heads, d).repeat_interleave(F_, 0)
+    ref = ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ V
+    close(_heads(o, nb, N, heads, d), ref, 1e-2, 1e-2, "xattn fwd")
+    do = rnd((nb * N, C), dev, 3)
+    (gq,) = torch.autograd.grad(ref, Q, _heads(do, nb, N, heads, d))
+    dq, _, _ = ops.attn_bwd(q, k, v, o, do, lse, N, Nk, heads, d, nb, kv_bdiv=F_, need_dkv=False)
+    close(_heads(dq, nb, N, heads, d), gq, 1e-2, 2e-2, "xattn dq")
+
+
+# ---------------------------------------------------------------------------------------------------
+def _temporal_ref(qkv, B, F_, HW, heads, d):
+    C = heads * d
+    t = qkv.float().reshape(B, F_, HW, 3, heads, d).permute(3, 0, 2, 4, 1, 5)  # [3, B, HW, heads, F, d]
+    return t[0].reshape(-1, heads, F_, d), t[1].reshape(-1, heads, F_, d), t[2].reshape(-1, heads, F_, d)
+
+
+def _temporal_unref(t, B, F_, HW, heads, d):  # [B*HW, heads, F, d] -> [(b f hw), heads*d]
+    return t.reshape(B, HW, heads, F_, d).permute(0, 3, 1, 2, 4).reshape(B * F_ * HW, heads * d)
+
+
+@pytest.mark.parametrize("F_,d", [(16, 40), (5, 16), (16, 160), (24, 32), (32, 80)])
+def test_temporal_attention_and_guidance(backend, F_, d):
+    dev = backend
+    B, HW, heads = (2, 6, 2) if not big(dev) else (2, 300, 8)
+    C = heads * d
+    qkv = rnd((B * F_ * HW, 3 * C), dev, 1, 0.8)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o = ops.tattn_fwd(q, k, v, B, F_, HW, heads, d)
+    Q, K, V = (t.requires_grad_() for t in _temporal_ref(qkv, B, F_, HW, heads, d))
+    P = ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1)  # [B*HW, heads, F, F]
+    ref = P @ V
+    close(o, _temporal_unref(ref, B, F_, HW, heads, d), 1e-2, 1e-2, "tattn fwd")
+
+    # extraction: top-1 of P (motionclone_functions.py:79)
+    val, idx = ops.tattn_top1(q, k, B, F_, HW, heads, d)
+    rv, ri = torch.topk(P, 1, -1)
+    close(val, rv, 2e-3, 2e-3, "top1 value")
+    mism = (idx.long().cpu() != ri.cpu())
+    if mism.any():  # only acceptable at numerical ties
+        p2 = torch.gather(P, -1, idx.long().to(P.device))
+        assert ((rv - p2).abs()[mism.to(rv.device)] < 1e-3).all(), "top1 index mismatch beyond a tie"
+
+    # loss + gradient with a perturbed reference representation
+    ref_idx = torch.randint(0, F_, ri.shape, generator=torch.Generator().manual_seed(7)).to(torch.uint8).to(dev)
+    ref_val = (torch.rand(ri.shape, generator=torch.Generator().manual_seed(8)) * 0.5).to(dev)
+    loss = ops.tattn_loss(q, k, ref_idx, ref_val, B, F_, HW, heads, d)
+    gathered = torch.gather(P, -1, ref_idx.long())
+    loss_ref = Fn.mse_loss(gathered, ref_val)
+    assert abs(loss.item() - loss_ref.item()) < 2e-3 * max(1.0, abs(loss_ref.item())) + 1e-5
+
+    weight = 300.0
+    do = rnd((B * F_ * HW, C), dev, 3)
+    dO = _temporal_ref(torch.cat([do, do, do], 1), B, F_, HW, heads, d)[0]
+    total = (ref * dO).sum() + weight * loss_ref
+    gq, gk, gv = torch.autograd.grad(total, (Q, K, V), retain_graph=True)
+    dqkv = torch.zeros_like(qkv)
+    coef = weight * 2.0 / gathered.numel()
+    ops.tattn_bwd(q, k, v, do, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, F_, HW, heads, d,
+                  ref_idx=ref_idx, ref_val=ref_val, seed_coef=coef)
+    close(dqkv[:, :C], _temporal_unref(gq, B, F_, HW, heads, d), 1e-2, 2e-2, "tattn dq")
+    close(dqkv[:, C:2 * C], _temporal_unref(gk, B, F_, HW, heads, d), 1e-2, 2e-2, "tattn dk")
+    close(dqkv[:, 2 * C:], _temporal_unref(gv, B, F_, HW, heads, d), 1e-2, 2e-2, "tattn dv")
+
+    # seed only (dO = NULL): what the last hooked attention of up_blocks.1 sees
+    gq2, gk2 = torch.autograd.grad(weight * Fn.mse_loss(torch.gather(P, -1, ref_idx.long()), ref_val), (Q, K))
+    d2 = torch.ones_like(qkv)
+    ops.tattn_bwd(q, k, v, None, d2[:, :C], d2[:, C:2 * C], d2[:, 2 * C:], B, F_, HW, heads, d,
+                  ref_idx=ref_idx, ref_val=ref_val, seed_coef=coef)
+    close(d2[:, :C], _temporal_unref(gq2, B, F_, HW, heads, d), 2e-3, 2e-2, "seed dq")
+    close(d2[:, C:2 * C], _temporal_unref(gk2, B, F_, HW, heads, d), 2e-3, 2e-2, "seed dk")
+    assert d2[:, 2 * C:].abs().max() == 0
+
+
+# ---------------------------------------------------------------------------------------------------
+def test_elementwise(backend):
+    dev = backend
+    M, D = (37, 64) if not big(dev) else (4099, 1280)
+    x = rnd((M, 2 * D), dev, 1)
+    xr = x.float().requires_grad_()
+    ref = xr[:, :D] * Fn.gelu(xr[:, D:])
+    close(ops.geglu_fwd(x), ref, 1e-2, 5e-3, "geglu")
+    dy = rnd((M, D), dev, 2)
+    (g,) = torch.autograd.grad(ref, xr, dy.float())
+    close(ops.geglu_bwd(dy, x), g, 1e-2, 1e-2, "geglu bwd")
+    a, b = rnd((M, D), dev, 3), rnd((M, D), dev, 4)
+    close(ops.add(a, b, sa=0.5, sb=2.0), 0.5 * a.float() + 2 * b.float(), 1e-2, 2e-3, "add")
+    close(ops.silu(a), Fn.silu(a.float()), 1e-3, 2e-3, "silu")
+    NF, H, W, C = 2, 3, 5, 64
+    up = rnd((NF, C, 2 * H, 2 * W), dev, 5)
+    close(_from_cl(ops.sumpool2(_to_cl(up), NF, H, W), NF, H, W), Fn.avg_pool2d(up.float(), 2) * 4, 1e-2, 2e-3, "sumpool")
+    lat = rnd((2, 4, 3, 5, 6), dev, 6)
+    cl = ops.latent_to_cl(lat, 64)
+    assert cl.shape == (2 * 3 * 30, 64) and cl[:, 4:].abs().max() == 0
+    back = ops.cl_to_latent(cl, 2, 4, 3, 5, 6)
+    assert torch.equal(back, lat)
+    t = torch.tensor([400.0, 37.0], device=dev)
+    emb = ops.timestep_embed(t, 320, lat)
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(160, device=dev).float() / 160)
+    e = t[:, None] * freqs[None]
+    close(emb, torch.cat([torch.cos(e), torch.sin(e)], -1), 2e-3, 2e-3, "timestep embedding")
+
+
+def test_cfg_ddim_step(backend):
+    dev = backend
+    CL, F_, H, W = 4, 3, 5, 6
+    x = rnd((1, CL, F_, H, W), dev, 1)
+    ec = rnd((1, CL, F_, H, W), dev, 2)
+    eu = rnd((1, CL, F_, H, W), dev, 3)
+    score = torch.randn(1, CL, F_, H, W, generator=torch.Generator().manual_seed(4)).to(dev)
+    ec_cl, eu_cl = ops.latent_to_cl(ec, 64), ops.latent_to_cl(eu, 64)
+    a_t, a_prev, cfg, gs = 0.31, 0.42, 7.5, 1.0
+    out = ops.cfg_ddim_step(ec_cl, eu_cl, x, score, cfg, a_t, a_prev, gs * math.sqrt(1 - a_t))
+    eps = ec.float() + cfg * (ec.float() - eu.float())
+    x0 = (x.float() - math.sqrt(1 - a_t) * eps) / math.sqrt(a_t)
+    eps2 = eps - gs * math.sqrt(1 - a_t) * score
+    ref = math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps2
+    close(out, ref, 2e-2, 3e-3, "cfg+ddim guided")
+    out2 = ops.cfg_ddim_step(ec_cl, eu_cl, x, None, cfg, a_t, a_prev, 0.0)
+    close(out2, math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps, 2e-2, 3e-3, "cfg+ddim plain")
