@@ -424,6 +424,7 @@ static void a_launch_dkdv(const AParams& P, const half_t* dO, int lddo, const fl
         case 1: CALL(1); break;          \
         case 2: CALL(2); break;          \
         case 3: CALL(3); break;          \
+        case 4: CALL(4); break;          \
         case 5: CALL(5); break;          \
         case 10: CALL(10); break;        \
         default: return MC_ERR_UNSUPPORTED; \

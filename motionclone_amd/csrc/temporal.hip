@@ -412,11 +412,13 @@ static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* d
         case 1 * 16 + 1: CALL(1, 1); break;                                     \
         case 1 * 16 + 2: CALL(1, 2); break;                                     \
         case 1 * 16 + 3: CALL(1, 3); break;                                     \
+        case 1 * 16 + 4: CALL(1, 4); break;                                     \
         case 1 * 16 + 5: CALL(1, 5); break;                                     \
         case 1 * 16 + 10: CALL(1, 10); break;                                   \
         case 2 * 16 + 1: CALL(2, 1); break;                                     \
         case 2 * 16 + 2: CALL(2, 2); break;                                     \
         case 2 * 16 + 3: CALL(2, 3); break;                                     \
+        case 2 * 16 + 4: CALL(2, 4); break;                                     \
         case 2 * 16 + 5: CALL(2, 5); break;                                     \
         case 2 * 16 + 10: CALL(2, 10); break;                                   \
         default: return MC_ERR_UNSUPPORTED;                                     \

@@ -1,0 +1,546 @@
+"""Execution engine of the guided-DDIM hot path on MI355X.
+
+One `UNet3DEngine` holds the packed fp16 weights of a reference `UNet3DConditionModel`
+(reference/motionclone/models/unet.py:38-249) and runs
+
+  * `forward`      - unet_customized_forward (motionclone_functions.py:478-662) as a fixed sequence of
+                     HIP kernel launches over channels-last token matrices [(b f y x), C];
+  * `backward`     - the data-gradient of the guidance loss w.r.t. the latent, i.e. what
+                     torch.autograd.grad does at motionclone_functions.py:236, as a hand-written
+                     reverse schedule (a tape of closures recorded by the in-graph half of the
+                     forward: conv_in .. up_blocks[guidance_block]); weight gradients are never formed;
+  * `guided_step` / `plain_step` / `extract_representation` - single_step_video (:173-257) and the
+                     model part of obtain_motion_representation (:74-79).
+
+Layout decisions: activations never leave [tokens, C]; the reference's einops
+round-trips, head reshapes, skip `torch.cat`s and the nearest-2x upsample are index math inside the
+kernels; q|k|v projections are fused into one GEMM; the 22 time_emb_proj Linears are one GEMM per
+forward and enter conv1 as a per-batch bias; gradients are carried at `grad_scale` x their value so
+fp16 gradient activations stay in range (the scale is divided out in the last kernel).
+"""
+import math
+
+import torch
+
+from . import ops
+
+DENSE, CONV_S1, CONV_S2, CONV_UP, TCONV_S2 = ops.DENSE, ops.CONV_S1, ops.CONV_S2, ops.CONV_UP, ops.TCONV_S2
+CIN_PAD = 64
+
+
+def default_config():
+    """SD-1.5 UNet + configs/model_config/model_config.yaml (the only architecture the reference ships)."""
+    return dict(in_channels=4, out_channels=4, block_out_channels=(320, 640, 1280, 1280), layers_per_block=2,
+                cross_attention_dim=768, attention_heads=8, norm_num_groups=32, norm_eps=1e-5,
+                down_has_attn=(True, True, True, False), up_has_attn=(False, True, True, True),
+                motion_heads=8, motion_pe_max_len=32, motion_mid_block=False)
+
+
+class Geo:
+    """token geometry of one resolution level"""
+
+    def __init__(self, B, F, H, W):
+        self.B, self.F, self.H, self.W = B, F, H, W
+        self.frames = B * F
+        self.hw = H * W
+        self.T = self.frames * self.hw
+
+    def down(self):
+        return Geo(self.B, self.F, self.H // 2, self.W // 2)
+
+    def up(self):
+        return Geo(self.B, self.F, self.H * 2, self.W * 2)
+
+
+def _pe_table(max_len, dim):
+    pos = torch.arange(max_len, dtype=torch.float32).unsqueeze(1)
+    div = torch.exp(torch.arange(0, dim, 2, dtype=torch.float32) * (-math.log(10000.0) / dim))
+    pe = torch.zeros(max_len, dim)
+    pe[:, 0::2] = torch.sin(pos * div)
+    pe[:, 1::2] = torch.cos(pos * div)
+    return pe
+
+
+class Weights:
+    """Packs a reference state-dict into kernel layouts on `device` (load-time only)."""
+
+    def __init__(self, sd, cfg, device):
+        self.sd = sd
+        self.cfg = cfg
+        self.dev = device
+        self._c = {}
+
+    def _get(self, key, fn):
+        if key not in self._c:
+            self._c[key] = fn()
+        return self._c[key]
+
+    def _h(self, t):
+        return t.detach().to(self.dev, torch.float16).contiguous()
+
+    def _f(self, t):
+        return t.detach().to(self.dev, torch.float32).contiguous()
+
+    def vec(self, name):
+        return self._get(("vec", name), lambda: self._f(self.sd[name]))
+
+    def lin(self, name):
+        """nn.Linear / 1x1 conv weight as [N, K]"""
+        return self._get(("lin", name), lambda: self._h(self.sd[name].reshape(self.sd[name].shape[0], -1)))
+
+    def lin_t(self, name):
+        """transposed copy [K, N] for the data-gradient GEMM"""
+        return self._get(("lin_t", name),
+                         lambda: self._h(self.sd[name].reshape(self.sd[name].shape[0], -1).t()))
+
+    def cat_lin(self, names):
+        return self._get(("cat", tuple(names)), lambda: self._h(torch.cat([self.sd[n] for n in names], 0)))
+
+    def cat_lin_t(self, names):
+        return self._get(("cat_t", tuple(names)), lambda: self._h(torch.cat([self.sd[n] for n in names], 0).t()))
+
+    def conv(self, name, pad_cin=0):
+        def mk():
+            w = self.sd[name].to(torch.float32).permute(0, 2, 3, 1)  # [Cout, 3, 3, Cin]
+            if pad_cin and w.shape[3] < pad_cin:
+                w = torch.nn.functional.pad(w, (0, pad_cin - w.shape[3]))
+            return self._h(w.reshape(w.shape[0], -1))
+        return self._get(("conv", name, pad_cin), mk)
+
+    def conv_dgrad(self, name, stride=1, pad_cin=0):
+        """[Cin, 9*Cout]: flipped taps for stride 1 (a conv again), plain taps for the stride-2 transpose"""
+        def mk():
+            w = self.sd[name].to(torch.float32)
+            if stride == 1:
+                w = w.flip(2, 3)
+            w = w.permute(1, 2, 3, 0)  # [Cin, 3, 3, Cout]
+            w = w.reshape(w.shape[0], -1)
+            if pad_cin and w.shape[0] < pad_cin:
+                w = torch.nn.functional.pad(w, (0, 0, 0, pad_cin - w.shape[0]))
+            return self._h(w)
+        return self._get(("conv_d", name, stride, pad_cin), mk)
+
+    def pe(self, dim):
+        return self._get(("pe", dim), lambda: self._f(_pe_table(self.cfg["motion_pe_max_len"], dim)))
+
+
+class Tape:
+    """reverse schedule: closures appended in forward order, run backwards; grads keyed by tensor identity"""
+
+    def __init__(self):
+        self.fns = []
+        self.grads = {}
+        self.keep = []
+
+    def add(self, fn):
+        self.fns.append(fn)
+
+    def give(self, x, dx):
+        """accumulate dx into the gradient of activation x"""
+        key = id(x)
+        if key in self.grads:
+            g = self.grads[key]
+            ops.add(g, dx, out=g)
+        else:
+            self.grads[key] = dx
+            self.keep.append(x)
+
+    def take(self, x):
+        return self.grads.pop(id(x), None)
+
+    def run(self):
+        for fn in reversed(self.fns):
+            fn()
+        self.fns = []
+
+
+class UNet3DEngine:
+    def __init__(self, state_dict, cfg=None, device="cuda", guidance_block=1, grad_scale=1024.0):
+        self.cfg = dict(cfg or default_config())
+        self.dev = torch.device(device)
+        self.w = Weights(state_dict, self.cfg, self.dev)
+        self.guidance_block = guidance_block
+        self.grad_scale = float(grad_scale)
+        self.G = self.cfg["norm_num_groups"]
+        assert self.G == 32, "kernels are specialised for GroupNorm(32)"
+        ch = self.cfg["block_out_channels"]
+        assert all(c % 64 == 0 for c in ch) and self.cfg["cross_attention_dim"] % 64 == 0
+        self._build_temb_plan()
+
+    # ---- time embedding: all time_emb_proj Linears as one GEMM ----------------------------------
+    def _resnet_names(self):
+        L = self.cfg["layers_per_block"]
+        names = []
+        for i in range(4):
+            names += ["down_blocks.%d.resnets.%d." % (i, j) for j in range(L)]
+        names += ["mid_block.resnets.0.", "mid_block.resnets.1."]
+        for i in range(4):
+            names += ["up_blocks.%d.resnets.%d." % (i, j) for j in range(L + 1)]
+        return names
+
+    def _build_temb_plan(self):
+        sd = self.w.sd
+        names = self._resnet_names()
+        self.temb_off = {}
+        off = 0
+        for n in names:
+            c = sd[n + "time_emb_proj.weight"].shape[0]
+            self.temb_off[n] = (off, c)
+            off += c
+        self.temb_w = self.w.cat_lin([n + "time_emb_proj.weight" for n in names])
+        self.temb_b = torch.cat([sd[n + "time_emb_proj.bias"].float() + sd[n + "conv1.bias"].float()
+                                 for n in names]).to(self.dev).contiguous()
+
+    def _time_bias(self, t, B, like):
+        """-> fp32 [B, sum Cout]: conv1.bias + time_emb_proj(silu(time_embedding(t)))  (resnet.py:191-195)"""
+        w = self.w
+        tt = torch.full((B,), float(t), dtype=torch.float32, device=self.dev)
+        e = ops.timestep_embed(tt, self.cfg["block_out_channels"][0], like)
+        e = ops.gemm(e, w.lin("time_embedding.linear_1.weight"), bias=w.vec("time_embedding.linear_1.bias").unsqueeze(0))
+        e = ops.gemm(ops.silu(e), w.lin("time_embedding.linear_2.weight"),
+                     bias=w.vec("time_embedding.linear_2.bias").unsqueeze(0))
+        allp = ops.gemm(ops.silu(e), self.temb_w)
+        return (allp.float() + self.temb_b.unsqueeze(0)).contiguous()
+
+    # ---- modules -----------------------------------------------------------------------------------
+    def _resnet(self, p, x, x2, tb_all, geo, tape):
+        """ResnetBlock3D.forward (resnet.py:183-213); x2 = skip tensor of the up-block concat or None"""
+        w, cfg = self.w, self.cfg
+        eps = cfg["norm_eps"]
+        fr, hw, H, W = geo.frames, geo.hw, geo.H, geo.W
+        off, cout = self.temb_off[p]
+        tb = tb_all[:, off:off + cout].contiguous()
+        g1, b1 = w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias")
+        g2, b2 = w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias")
+        st1 = ops.gn_stats(x, x2, fr, hw, eps)
+        h1 = ops.gn_apply(x, x2, st1, g1, b1, True, fr, hw)
+        h2 = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=geo.F * hw, mode=CONV_S1,
+                      geom=(H, W, H, W), m_out=geo.T)
+        del h1
+        st2 = ops.gn_stats(h2, None, fr, hw, eps)
+        h3 = ops.gn_apply(h2, None, st2, g2, b2, True, fr, hw)
+        has_sc = (p + "conv_shortcut.weight") in w.sd
+        if has_sc:
+            sc = ops.gemm(x, w.lin(p + "conv_shortcut.weight"), a2=x2,
+                          bias=w.vec(p + "conv_shortcut.bias").unsqueeze(0))
+        else:
+            assert x2 is None
+            sc = x
+        out = ops.gemm(h3, w.conv(p + "conv2.weight"), bias=w.vec(p + "conv2.bias").unsqueeze(0), residual=sc,
+                       mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
+        if tape is not None:
+            def bwd():
+                dout = tape.take(out)
+                if dout is None:
+                    return
+                dh3 = ops.gemm(dout, w.conv_dgrad(p + "conv2.weight"), mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
+                dh2 = ops.gn_bwd(h2, None, dh3, st2, g2, b2, True, fr, hw)
+                dh1 = ops.gemm(dh2, w.conv_dgrad(p + "conv1.weight"), mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
+                if has_sc:
+                    dx = ops.gn_bwd(x, x2, dh1, st1, g1, b1, True, fr, hw)
+                    ops.gemm(dout, w.lin_t(p + "conv_shortcut.weight"), residual=dx, out=dx)
+                else:
+                    dx = ops.gn_bwd(x, None, dh1, st1, g1, b1, True, fr, hw, out=dout, accumulate=True)
+                c1 = x.shape[1]
+                if x2 is None:
+                    tape.give(x, dx)
+                else:
+                    tape.give(x, dx[:, :c1])
+                    tape.give(x2, dx[:, c1:])
+            tape.add(bwd)
+        return out
+
+    def _spatial(self, p, x, text2d, n_text, geo, tape):
+        """Transformer3DModel + BasicTransformerBlock (attention.py:95-142,256-300)"""
+        w, cfg = self.w, self.cfg
+        heads = cfg["attention_heads"]
+        C = x.shape[1]
+        d = C // heads
+        fr, hw, T = geo.frames, geo.hw, geo.T
+        b = p + "transformer_blocks.0."
+        gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
+        st = ops.gn_stats(x, None, fr, hw, 1e-6)
+        hn = ops.gn_apply(x, None, st, gN, bN, False, fr, hw)
+        h0 = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
+        del hn
+        # self-attention
+        n1, ls1 = ops.layernorm_fwd(h0, w.vec(b + "norm1.weight"), w.vec(b + "norm1.bias"), save_stats=tape is not None)
+        qkv = ops.gemm(n1, w.cat_lin([b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"]))
+        del n1
+        a1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], hw, hw, heads, d, fr,
+                                need_lse=tape is not None)
+        h1 = ops.gemm(a1, w.lin(b + "attn1.to_out.0.weight"), bias=w.vec(b + "attn1.to_out.0.bias").unsqueeze(0),
+                      residual=h0)
+        # cross-attention to the text (K/V are frame-invariant: computed once per batch element)
+        n2, ls2 = ops.layernorm_fwd(h1, w.vec(b + "norm2.weight"), w.vec(b + "norm2.bias"), save_stats=tape is not None)
+        q2 = ops.gemm(n2, w.lin(b + "attn2.to_q.weight"))
+        del n2
+        kv = ops.gemm(text2d, w.cat_lin([b + "attn2.to_k.weight", b + "attn2.to_v.weight"]))
+        a2, lse2 = ops.attn_fwd(q2, kv[:, :C], kv[:, C:], hw, n_text, heads, d, fr, kv_bdiv=geo.F,
+                                need_lse=tape is not None)
+        h2 = ops.gemm(a2, w.lin(b + "attn2.to_out.0.weight"), bias=w.vec(b + "attn2.to_out.0.bias").unsqueeze(0),
+                      residual=h1)
+        # GEGLU feed-forward
+        n3, ls3 = ops.layernorm_fwd(h2, w.vec(b + "norm3.weight"), w.vec(b + "norm3.bias"), save_stats=tape is not None)
+        ff1 = ops.gemm(n3, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
+        del n3
+        gg = ops.geglu_fwd(ff1)
+        h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
+        del gg
+        out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)
+        if tape is None:
+            return out
+
+        def bwd():
+            dout = tape.take(out)
+            if dout is None:
+                return
+            dh3 = ops.gemm(dout, w.lin_t(p + "proj_out.weight"))
+            dg = ops.gemm(dh3, w.lin_t(b + "ff.net.2.weight"))
+            dff1 = ops.geglu_bwd(dg, ff1)
+            dn3 = ops.gemm(dff1, w.lin_t(b + "ff.net.0.proj.weight"))
+            dh2 = ops.layernorm_bwd(dn3, h2, ls3, w.vec(b + "norm3.weight"), add=dh3)
+            da2 = ops.gemm(dh2, w.lin_t(b + "attn2.to_out.0.weight"))
+            dq2, _, _ = ops.attn_bwd(q2, kv[:, :C], kv[:, C:], a2, da2, lse2, hw, n_text, heads, d, fr,
+                                     kv_bdiv=geo.F, need_dkv=False)
+            dn2 = ops.gemm(dq2, w.lin_t(b + "attn2.to_q.weight"))
+            dh1 = ops.layernorm_bwd(dn2, h1, ls2, w.vec(b + "norm2.weight"), add=dh2)
+            da1 = ops.gemm(dh1, w.lin_t(b + "attn1.to_out.0.weight"))
+            dqkv = ops.empty((T, 3 * C), x)
+            ops.attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a1, da1, lse1, hw, hw, heads, d, fr,
+                         dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+            dn1 = ops.gemm(dqkv, w.cat_lin_t([b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"]))
+            dh0 = ops.layernorm_bwd(dn1, h0, ls1, w.vec(b + "norm1.weight"), add=dh1)
+            dhn = ops.gemm(dh0, w.lin_t(p + "proj_in.weight"))
+            dx = ops.gn_bwd(x, None, dhn, st, gN, bN, False, fr, hw, out=dout, accumulate=True)
+            tape.give(x, dx)
+        tape.add(bwd)
+        return out
+
+    def _motion(self, name, x, geo, tape, record, seeds):
+        """VanillaTemporalModule (motion_module.py:80-85,137-161,213-225,274-345).
+        record: dict collecting the fused q|k|v buffer of hooked attentions (MySelfAttnProcessor.record_qkv);
+        seeds: {attention name: (ref_idx u8, ref_val f32, coef)} guidance seeds for the backward."""
+        w, cfg = self.w, self.cfg
+        heads = cfg["motion_heads"]
+        C = x.shape[1]
+        d = C // heads
+        fr, hw, T = geo.frames, geo.hw, geo.T
+        p = name + ".temporal_transformer."
+        b = p + "transformer_blocks.0."
+        gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
+        pe = w.pe(C)[:geo.F].contiguous()
+        st = ops.gn_stats(x, None, fr, hw, 1e-6)
+        hn = ops.gn_apply(x, None, st, gN, bN, False, fr, hw)
+        h = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
+        del hn
+        saved = []
+        for a in range(2):
+            ap = b + "attention_blocks.%d." % a
+            aname = ap[:-1]
+            n, ls = ops.layernorm_fwd(h, w.vec(b + "norms.%d.weight" % a), w.vec(b + "norms.%d.bias" % a), pe=pe, hw=hw,
+                                      save_stats=tape is not None)
+            qkv = ops.gemm(n, w.cat_lin([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]))
+            del n
+            if record is not None:
+                record[aname] = dict(qkv=qkv, C=C, heads=heads, d=d, geo=geo)
+            o = ops.tattn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], geo.B, geo.F, hw, heads, d)
+            hnext = ops.gemm(o, w.lin(ap + "to_out.0.weight"), bias=w.vec(ap + "to_out.0.bias").unsqueeze(0), residual=h)
+            saved.append((h, ls, qkv, aname, ap))
+            h = hnext
+        h2 = h
+        n, lsf = ops.layernorm_fwd(h2, w.vec(b + "ff_norm.weight"), w.vec(b + "ff_norm.bias"), save_stats=tape is not None)
+        ff1 = ops.gemm(n, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
+        del n
+        gg = ops.geglu_fwd(ff1)
+        h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
+        del gg
+        out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)
+        if tape is None:
+            return out
+
+        def bwd():
+            dout = tape.take(out)
+            has_seed = seeds is not None and any(s[3] in seeds for s in saved)
+            if dout is None and not has_seed:
+                return
+            dh = None
+            if dout is not None:
+                dh3 = ops.gemm(dout, w.lin_t(p + "proj_out.weight"))
+                dg = ops.gemm(dh3, w.lin_t(b + "ff.net.2.weight"))
+                dff1 = ops.geglu_bwd(dg, ff1)
+                dn = ops.gemm(dff1, w.lin_t(b + "ff.net.0.proj.weight"))
+                dh = ops.layernorm_bwd(dn, h2, lsf, w.vec(b + "ff_norm.weight"), add=dh3)
+            for a in (1, 0):
+                hin, ls, qkv, aname, ap = saved[a]
+                seed = seeds.get(aname) if seeds is not None else None
+                if dh is None and seed is None:
+                    continue
+                da = ops.gemm(dh, w.lin_t(ap + "to_out.0.weight")) if dh is not None else None
+                dqkv = ops.empty((T, 3 * C), x)
+                ops.tattn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], da, dqkv[:, :C], dqkv[:, C:2 * C],
+                              dqkv[:, 2 * C:], geo.B, geo.F, hw, heads, d,
+                              ref_idx=seed[0] if seed else None, ref_val=seed[1] if seed else None,
+                              seed_coef=seed[2] if seed else 0.0)
+                dn = ops.gemm(dqkv, w.cat_lin_t([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]))
+                dh = ops.layernorm_bwd(dn, hin, ls, w.vec(b + "norms.%d.weight" % a), add=dh)
+            dhn = ops.gemm(dh, w.lin_t(p + "proj_in.weight"))
+            if dout is not None:
+                dx = ops.gn_bwd(x, None, dhn, st, gN, bN, False, fr, hw, out=dout, accumulate=True)
+            else:
+                dx = ops.gn_bwd(x, None, dhn, st, gN, bN, False, fr, hw)
+            tape.give(x, dx)
+        tape.add(bwd)
+        return out
+
+    def _downsample(self, p, x, geo, tape):
+        w = self.w
+        g2 = geo.down()
+        out = ops.gemm(x, w.conv(p + "weight"), bias=w.vec(p + "bias").unsqueeze(0), mode=CONV_S2,
+                       geom=(geo.H, geo.W, g2.H, g2.W), m_out=g2.T)
+        if tape is not None:
+            def bwd():
+                dout = tape.take(out)
+                if dout is None:
+                    return
+                dx = ops.gemm(dout, w.conv_dgrad(p + "weight", stride=2), mode=TCONV_S2,
+                              geom=(g2.H, g2.W, geo.H, geo.W), m_out=geo.T)
+                tape.give(x, dx)
+            tape.add(bwd)
+        return out, g2
+
+    def _upsample(self, p, x, geo, tape):
+        w = self.w
+        g2 = geo.up()
+        out = ops.gemm(x, w.conv(p + "weight"), bias=w.vec(p + "bias").unsqueeze(0), mode=CONV_UP,
+                       geom=(geo.H, geo.W, g2.H, g2.W), m_out=g2.T)
+        if tape is not None:
+            def bwd():
+                dout = tape.take(out)
+                if dout is None:
+                    return
+                du = ops.gemm(dout, w.conv_dgrad(p + "weight"), mode=CONV_S1, geom=(g2.H, g2.W, g2.H, g2.W), m_out=g2.T)
+                tape.give(x, ops.sumpool2(du, geo.frames, geo.H, geo.W))
+            tape.add(bwd)
+        return out, g2
+
+    # ---- whole network --------------------------------------------------------------------------------
+    def forward(self, latents, t, text, tape=None, record=None, seeds=None, only_motion_feature=False,
+                down_residuals=None, mid_residual=None):
+        """latents [B, 4, F, H, W] fp16, text [B, n_text, xdim] fp16 -> eps as a token matrix [(b f y x), 4].
+        With `tape`, the blocks up to up_blocks[guidance_block] record their backward (motionclone_functions.py
+        :601-625); later blocks never do (the reference runs them under no_grad, :629-652)."""
+        cfg, w = self.cfg, self.w
+        assert latents.dtype == torch.float16 and text.dtype == torch.float16
+        B, CL, F, H, W = latents.shape
+        L = cfg["layers_per_block"]
+        geo = Geo(B, F, H, W)
+        n_text = text.shape[1]
+        text2d = text.reshape(B * n_text, text.shape[2]).contiguous()
+        tb_all = self._time_bias(t, B, latents)
+        gb = self.guidance_block
+        hooked = "up_blocks.%d" % gb
+
+        x_in = ops.latent_to_cl(latents, CIN_PAD)
+        x = ops.gemm(x_in, w.conv("conv_in.weight", CIN_PAD), bias=w.vec("conv_in.bias").unsqueeze(0), mode=CONV_S1,
+                     geom=(H, W, H, W), m_out=geo.T)
+        if tape is not None:
+            x0 = x
+
+            def bwd_in():
+                dout = tape.take(x0)
+                if dout is None:
+                    return
+                dxin = ops.gemm(dout, w.conv_dgrad("conv_in.weight", pad_cin=CIN_PAD), mode=CONV_S1,
+                                geom=(H, W, H, W), m_out=geo.T)
+                tape.latent_grad = ops.cl_to_latent(dxin, B, CL, F, H, W, scale=1.0 / self.grad_scale, f32=True)
+            tape.add(bwd_in)
+        skips = [(x, geo)]
+        for i in range(4):
+            for j in range(L):
+                x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, tape)
+                if cfg["down_has_attn"][i]:
+                    x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, tape)
+                x = self._motion("down_blocks.%d.motion_modules.%d" % (i, j), x, geo, tape, None, None)
+                skips.append((x, geo))
+            if i < 3:
+                x, geo = self._downsample("down_blocks.%d.downsamplers.0.conv." % i, x, geo, tape)
+                skips.append((x, geo))
+        if down_residuals is not None:
+            raise NotImplementedError("SparseCtrl residuals: SURVEY.md 8a A16 is scheduled after the t2v path")
+        x = self._resnet("mid_block.resnets.0.", x, None, tb_all, geo, tape)
+        x = self._spatial("mid_block.attentions.0.", x, text2d, n_text, geo, tape)
+        x = self._resnet("mid_block.resnets.1.", x, None, tb_all, geo, tape)
+        for i in range(4):
+            in_graph = i <= gb
+            if not in_graph and only_motion_feature:
+                return None
+            tp = tape if in_graph else None
+            for j in range(L + 1):
+                skip, sgeo = skips.pop()
+                assert sgeo.T == geo.T
+                x = self._resnet("up_blocks.%d.resnets.%d." % (i, j), x, skip, tb_all, geo, tp)
+                if cfg["up_has_attn"][i]:
+                    x = self._spatial("up_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, tp)
+                nm = "up_blocks.%d.motion_modules.%d" % (i, j)
+                is_hooked = hooked in nm
+                x = self._motion(nm, x, geo, tp, record if is_hooked else None, seeds if is_hooked else None)
+            if i < 3:
+                # the upsampler of block i feeds block i+1: in the graph only while i+1 <= guidance block
+                x, geo = self._upsample("up_blocks.%d.upsamplers.0.conv." % i, x, geo, tape if i < gb else None)
+        st = ops.gn_stats(x, None, geo.frames, geo.hw, cfg["norm_eps"])
+        hn = ops.gn_apply(x, None, st, w.vec("conv_norm_out.weight"), w.vec("conv_norm_out.bias"), True, geo.frames, geo.hw)
+        eps = ops.gemm(hn, w.conv("conv_out.weight"), bias=w.vec("conv_out.bias").unsqueeze(0), mode=CONV_S1,
+                       geom=(geo.H, geo.W, geo.H, geo.W), m_out=geo.T)
+        return eps
+
+    # ---- guidance layer -----------------------------------------------------------------------------------
+    def hooked_names(self):
+        L = self.cfg["layers_per_block"]
+        return ["up_blocks.%d.motion_modules.%d.temporal_transformer.transformer_blocks.0.attention_blocks.%d"
+                % (self.guidance_block, j, a) for j in range(L + 1) for a in range(2)]
+
+    def extract_representation(self, noisy_latents, t, uncond_text):
+        """model part of obtain_motion_representation (motionclone_functions.py:74-79): partial forward to the
+        guidance block, P = softmax(scale q k^T) of the hooked temporal attentions, top-1 value/index."""
+        record = {}
+        self.forward(noisy_latents, t, uncond_text, record=record, only_motion_feature=True)
+        rep = {}
+        for name in self.hooked_names():
+            r = record[name]
+            C, g = r["C"], r["geo"]
+            val, idx = ops.tattn_top1(r["qkv"][:, :C], r["qkv"][:, C:2 * C], g.B, g.F, g.hw, r["heads"], r["d"])
+            rep[name] = [val, idx]
+        return rep
+
+    def prepare_representation(self, rep):
+        """reference .pt dict {name: [values [BN, heads, F, 1], indices uint8]} -> device tensors for the kernels"""
+        out = {}
+        for name, (val, idx) in rep.items():
+            out[name] = (idx.to(self.dev, torch.uint8).contiguous(), val.to(self.dev, torch.float32).contiguous())
+        return out
+
+    def guided_eps_and_grad(self, latents, t, text_cond, rep_dev, weight, want_loss=False):
+        """eps_c forward with the in-graph half taped + backward of  weight * sum_m mse_m  w.r.t. the latent
+        (motionclone_functions.py:221-236).  Returns (eps_c tokens, grad fp32 [1,4,F,H,W], loss or None)."""
+        tape = Tape()
+        seeds = {}
+        for name, (idx, val) in rep_dev.items():
+            numel = idx.numel()
+            seeds[name] = (idx, val, self.grad_scale * float(weight) * 2.0 / numel)
+        record = {}
+        eps_c = self.forward(latents, t, text_cond, tape=tape, record=record, seeds=seeds)
+        loss = None
+        if want_loss:
+            total = None
+            for name, (idx, val) in rep_dev.items():
+                r = record[name]
+                C, g = r["C"], r["geo"]
+                lm = ops.tattn_loss(r["qkv"][:, :C], r["qkv"][:, C:2 * C], idx, val, g.B, g.F, g.hw, r["heads"], r["d"])
+                total = lm if total is None else total + lm
+            loss = total * float(weight)
+        tape.latent_grad = None
+        tape.run()
+        grad = tape.latent_grad
+        assert grad is not None, "guidance gradient did not reach the latent"
+        return eps_c, grad, loss

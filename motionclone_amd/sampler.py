@@ -1,0 +1,92 @@
+"""Guided DDIM sampler over `UNet3DEngine`: the loop of sample_video / single_step_video
+(reference motionclone/utils/motionclone_functions.py:102-257) with the scheduler arithmetic of
+schedule_set_timesteps (:413-472) and schedule_customized_step (:285-409) folded into one fused
+CFG + DDIM kernel per step.  Host side is pure orchestration: per step it computes six scalars.
+"""
+import numpy as np
+import torch
+
+from . import ops
+
+
+def ddim_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
+    """DDIMScheduler(beta_schedule='linear') state as configured at configs/model_config/model_config.yaml:16-21
+    (diffusers 0.16.0 semantics: fp32 linspace -> cumprod); final_alpha_cumprod = 1 (set_alpha_to_one)."""
+    betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+    return torch.cumprod(1.0 - betas, dim=0)
+
+
+def uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale, num_train_timesteps=1000):
+    """timestep_spacing_type == 'uneven' (motionclone_functions.py:432-445): dense steps while guiding."""
+    if num_inference_steps > num_train_timesteps:
+        raise ValueError("num_inference_steps %d exceeds num_train_timesteps %d" % (num_inference_steps,
+                                                                                  num_train_timesteps))
+    split = int((1 - guidance_scale) * num_train_timesteps)
+    a = np.linspace(split, num_train_timesteps - 1, guidance_steps).round()[::-1].copy().astype(np.int64)
+    b = np.linspace(0, split - 1, num_inference_steps - guidance_steps).round()[::-1].copy().astype(np.int64)
+    return np.concatenate((a, b))
+
+
+class MotionCloneSampler:
+    def __init__(self, engine, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
+                 num_inference_steps=30, guidance_steps=18, guidance_scale=0.4, score_guidance_scale=1.0):
+        self.engine = engine
+        self.cfg_scale = float(cfg_scale)
+        self.weight = float(motion_guidance_weight)
+        self.warm, self.cool = warm_up_steps, cool_up_steps
+        self.N, self.G = num_inference_steps, guidance_steps
+        self.timesteps = uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale)
+        self.acp = ddim_alphas_cumprod()
+        self.final_alpha = 1.0
+        self.score_gs = float(score_guidance_scale)
+
+    def _alphas(self, i):
+        t = int(self.timesteps[i])
+        t_prev = int(self.timesteps[i + 1]) if i + 1 < len(self.timesteps) else -1
+        a_t = float(self.acp[t])
+        a_prev = float(self.acp[t_prev]) if t_prev >= 0 else self.final_alpha
+        return t, a_t, a_prev
+
+    def guidance_factor(self, i):
+        """warm-up / cool-down of the guidance loss (motionclone_functions.py:228-234; strict inequalities)"""
+        s = 1.0
+        if i < self.warm:
+            s *= (i + 1) / self.warm
+        if i > self.G - self.cool:
+            s *= (self.G - i) / self.cool
+        return s
+
+    def add_noise(self, t, x0, noise):
+        """add_noise (motionclone_functions.py:19-23)"""
+        a = float(self.acp[int(t)])
+        return (a ** 0.5 * x0.float() + (1 - a) ** 0.5 * noise.float()).to(x0.dtype)
+
+    def extract(self, video_latents, noise, uncond_text, add_noise_step=400):
+        noisy = self.add_noise(add_noise_step, video_latents, noise)
+        return self.engine.extract_representation(noisy, add_noise_step, uncond_text)
+
+    def step(self, latents, i, text, rep_dev, aux=None):
+        """single_step_video (motionclone_functions.py:173-257): text = [uncond, cond] embeddings [2, n, dim]"""
+        eng = self.engine
+        t, a_t, a_prev = self._alphas(i)
+        if i < self.G:
+            eps_u = eng.forward(latents, t, text[0:1])
+            w = self.weight * self.guidance_factor(i)
+            eps_c, grad, loss = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w, want_loss=aux is not None)
+            if aux is not None:
+                aux.update(eps_u=eps_u, eps_c=eps_c, grad=grad, loss=loss)
+            coef = self.score_gs * (1.0 - a_t) ** 0.5
+            return ops.cfg_ddim_step(eps_c, eps_u, latents, grad, self.cfg_scale, a_t, a_prev, coef)
+        eps2 = eng.forward(latents.expand(2, -1, -1, -1, -1), t, text)
+        T1 = eps2.shape[0] // 2
+        if aux is not None:
+            aux.update(eps_u=eps2[:T1], eps_c=eps2[T1:])
+        return ops.cfg_ddim_step(eps2[T1:], eps2[:T1], latents, None, self.cfg_scale, a_t, a_prev, 0.0)
+
+    def sample(self, latents, text, rep, progress=None):
+        rep_dev = self.engine.prepare_representation(rep)
+        for i in range(len(self.timesteps)):
+            latents = self.step(latents, i, text, rep_dev)
+            if progress is not None:
+                progress(i)
+        return latents

@@ -1,0 +1,156 @@
+"""Module-granularity parity (SURVEY.md 8c ii): each engine block (forward and hand-written data-gradient)
+against the oracle's restatement of the same reference module under torch.autograd."""
+import pytest
+import torch
+
+from motionclone_amd import engine as E
+from motionclone_amd import ops
+from oracle import unet3d_ref as U
+
+
+def cl(x):  # [B, C, F, H, W] -> tokens
+    B, C, F, H, W = x.shape
+    return x.permute(0, 2, 3, 4, 1).reshape(B * F * H * W, C).contiguous()
+
+
+def uncl(t, B, F, H, W):
+    return t.float().cpu().reshape(B, F, H, W, -1).permute(0, 4, 1, 2, 3)
+
+
+def rel(a, b):
+    return ((a.float().cpu() - b.float().cpu()).norm() / b.float().cpu().norm().clamp_min(1e-12)).item()
+
+
+@pytest.fixture
+def setup(backend):
+    cfg = dict(U.TINY_CONFIG)
+    sd = {k: v.half().float() for k, v in U.random_state_dict(cfg, seed=5).items()}
+    eng = E.UNet3DEngine(sd, cfg, backend)
+    return backend, cfg, sd, eng
+
+
+def rnd(shape, seed, s=1.0):
+    return (torch.randn(shape, generator=torch.Generator().manual_seed(seed)) * s).half()
+
+
+def run_bwd(tape, out, dout):
+    tape.grads[id(out)] = dout
+    tape.run()
+
+
+@pytest.mark.parametrize("name,cin,concat", [("down_blocks.0.resnets.0.", 64, 0), ("down_blocks.1.resnets.0.", 64, 0),
+                                             ("up_blocks.1.resnets.2.", 128, 128)])
+def test_resnet(setup, name, cin, concat):
+    dev, cfg, sd, eng = setup
+    B, F, H, W = 2, 3, 4, 6
+    geo = E.Geo(B, F, H, W)
+    x = rnd((B, cin, F, H, W), 1)
+    x2 = rnd((B, concat, F, H, W), 2) if concat else None
+    cout = sd[name + "conv1.weight"].shape[0]
+    tb_all = torch.zeros(B, sum(c for _, c in eng.temb_off.values()))
+    off, _ = eng.temb_off[name]
+    tproj = torch.randn(B, cout, generator=torch.Generator().manual_seed(3))
+    tb_all[:, off:off + cout] = tproj
+    tape = E.Tape()
+    xa, xb = cl(x).to(dev), (cl(x2).to(dev) if concat else None)
+    out = eng._resnet(name, xa, xb, tb_all.to(dev), geo, tape)
+    # oracle: feed a temb whose projection equals tproj - conv1.bias  (tb = conv1.bias + time_emb_proj(silu(temb)))
+    xin = torch.cat([x, x2], 1).float() if concat else x.float()
+    xin.requires_grad_()
+    sd2 = dict(sd)
+    sd2[name + "time_emb_proj.weight"] = torch.zeros_like(sd[name + "time_emb_proj.weight"])
+    ref = None
+    outs = []
+    for b in range(B):
+        sd2[name + "time_emb_proj.bias"] = tproj[b] - sd[name + "conv1.bias"]
+        outs.append(U.resnet_block(sd2, name, xin[b:b + 1], torch.zeros(1, sd[name + "time_emb_proj.weight"].shape[1]), cfg))
+    ref = torch.cat(outs, 0)
+    assert rel(uncl(out, B, F, H, W), ref) < 1e-2
+    dout = rnd(tuple(ref.shape), 4)
+    (gref,) = torch.autograd.grad(ref, xin, dout.float())
+    run_bwd(tape, out, cl(dout).to(dev))
+    gx = uncl(tape.grads[id(xa)], B, F, H, W)
+    if concat:
+        gx = torch.cat([gx, uncl(tape.grads[id(xb)], B, F, H, W)], 1)
+    assert rel(gx, gref) < 2e-2, rel(gx, gref)
+
+
+def test_spatial_transformer(setup):
+    dev, cfg, sd, eng = setup
+    name = "down_blocks.1.attentions.0."
+    B, F, H, W, C = 2, 3, 4, 6, 128
+    geo = E.Geo(B, F, H, W)
+    x = rnd((B, C, F, H, W), 1)
+    text = rnd((B, 7, cfg["cross_attention_dim"]), 2)
+    tape = E.Tape()
+    xa = cl(x).to(dev)
+    out = eng._spatial(name, xa, text.reshape(B * 7, -1).to(dev), 7, geo, tape)
+    xin = x.float().requires_grad_()
+    ref = U.spatial_transformer(sd, name, xin, text.float(), cfg)
+    assert rel(uncl(out, B, F, H, W), ref) < 1e-2
+    dout = rnd(tuple(ref.shape), 4)
+    (gref,) = torch.autograd.grad(ref, xin, dout.float())
+    run_bwd(tape, out, cl(dout).to(dev))
+    g = rel(uncl(tape.grads[id(xa)], B, F, H, W), gref)
+    assert g < 2e-2, g
+
+
+@pytest.mark.parametrize("with_dout", [True, False])
+def test_motion_module(setup, with_dout):
+    dev, cfg, sd, eng = setup
+    name = "up_blocks.1.motion_modules.1"
+    B, F, H, W, C = 1, 5, 3, 4, 128
+    heads = cfg["motion_heads"]
+    geo = E.Geo(B, F, H, W)
+    x = rnd((B, C, F, H, W), 1)
+    xin = x.float().requires_grad_()
+    rec = {}
+    ref = U.motion_module(sd, name + ".", xin, cfg, rec, name)
+    # guidance seeds on both attentions
+    from oracle import guidance_ref as G
+    prob = G.temp_attn_prob(rec, heads)
+    seeds, loss = {}, 0
+    weight = 50.0
+    for k, p in prob.items():
+        idx = torch.randint(0, F, p.shape[:-1] + (1,), generator=torch.Generator().manual_seed(9)).to(torch.uint8)
+        val = torch.rand(p.shape[:-1] + (1,), generator=torch.Generator().manual_seed(10)) * 0.5
+        loss = loss + weight * torch.nn.functional.mse_loss(torch.gather(p, -1, idx.long()), val)
+        seeds[k] = (idx.to(dev).contiguous(), val.to(dev).contiguous(), weight * 2.0 / idx.numel())
+    tape = E.Tape()
+    xa = cl(x).to(dev)
+    record = {}
+    out = eng._motion(name, xa, geo, tape, record, seeds)
+    assert rel(uncl(out, B, F, H, W), ref) < 1e-2
+    assert set(record) == set(prob)
+    dout = rnd(tuple(ref.shape), 4)
+    total = loss + ((ref * dout.float()).sum() if with_dout else 0)
+    (gref,) = torch.autograd.grad(total, xin)
+    if with_dout:
+        tape.grads[id(out)] = cl(dout).to(dev)
+    tape.run()
+    g = rel(uncl(tape.grads[id(xa)], B, F, H, W), gref)
+    assert g < 2e-2, g
+
+
+def test_down_up_sample(setup):
+    dev, cfg, sd, eng = setup
+    B, F, H, W = 1, 2, 4, 6
+    geo = E.Geo(B, F, H, W)
+    for kind, name in (("down", "down_blocks.0.downsamplers.0.conv."), ("up", "up_blocks.2.upsamplers.0.conv.")):
+        x = rnd((B, sd[name + "weight"].shape[1], F, H, W), 1)
+        xin = x.float().requires_grad_()
+        tape = E.Tape()
+        xa = cl(x).to(dev)
+        if kind == "down":
+            out, g2 = eng._downsample(name, xa, geo, tape)
+            ref = U._conv(sd, name, xin, stride=2)
+        else:
+            out, g2 = eng._upsample(name, xa, geo, tape)
+            u = torch.nn.functional.interpolate(U._to_frames(xin), scale_factor=2.0, mode="nearest")
+            ref = U._conv(sd, name, U._from_frames(u, B))
+        assert rel(uncl(out, B, F, g2.H, g2.W), ref) < 1e-2
+        dout = rnd(tuple(ref.shape), 4)
+        (gref,) = torch.autograd.grad(ref, xin, dout.float())
+        run_bwd(tape, out, cl(dout).to(dev))
+        g = rel(uncl(tape.grads[id(xa)], B, F, H, W), gref)
+        assert g < 2e-2, (kind, g)

@@ -1,0 +1,112 @@
+"""End-to-end parity of the HIP engine with the oracle on the tiny UNet3D: forward, motion-representation
+extraction, guidance loss + latent gradient, one guided and one plain DDIM step, a short loop.
+
+'emu' runs the kernel sources on the host simulator here; 'hip' (gpu-marked) runs the real library."""
+import pytest
+import torch
+
+from motionclone_amd.engine import UNet3DEngine
+from motionclone_amd.sampler import MotionCloneSampler
+from motionclone_amd import ops
+from oracle import guidance_ref as G
+from oracle import unet3d_ref as U
+
+HP = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10)
+
+
+def make_inputs(cfg, F=4, H=8, W=8, n_text=7):
+    lat = torch.randn(1, 4, F, H, W, generator=torch.Generator().manual_seed(2025))
+    text = torch.randn(2, n_text, cfg["cross_attention_dim"], generator=torch.Generator().manual_seed(7))
+    vid = 0.18215 * torch.randn(1, 4, F, H, W, generator=torch.Generator().manual_seed(11))
+    noise = torch.randn(1, 4, F, H, W, generator=torch.Generator().manual_seed(2025))
+    return lat, text, vid, noise
+
+
+def rel_err(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def to_lat(eps_tokens, B, F, H, W):
+    return ops.cl_to_latent(eps_tokens, B, 4, F, H, W).float().cpu()
+
+
+@pytest.fixture
+def tiny():
+    cfg = dict(U.TINY_CONFIG)
+    sd = U.random_state_dict(cfg, seed=1234)
+    # weights rounded to fp16 once, so oracle (fp32 math) and engine (fp16 storage) share identical parameters
+    sd = {k: v.half().float() for k, v in sd.items()}
+    return cfg, sd
+
+
+def test_forward_matches_oracle(backend, tiny):
+    dev = backend
+    cfg, sd = tiny
+    lat, text, _, _ = make_inputs(cfg)
+    lat16, text16 = lat.half(), text.half()
+    eng = UNet3DEngine(sd, cfg, dev)
+    eps = eng.forward(lat16.expand(2, -1, -1, -1, -1).to(dev), 701, text16.to(dev))
+    with torch.no_grad():
+        ref = U.unet_forward(sd, cfg, lat16.float().expand(2, -1, -1, -1, -1), 701, text16.float())
+    got = to_lat(eps, 2, 4, 8, 8)
+    assert rel_err(got, ref) < 2e-2, rel_err(got, ref)
+
+
+def test_extraction_matches_oracle(backend, tiny):
+    dev = backend
+    cfg, sd = tiny
+    _, text, vid, noise = make_inputs(cfg)
+    eng = UNet3DEngine(sd, cfg, dev)
+    smp = MotionCloneSampler(eng, num_inference_steps=4, guidance_steps=2, guidance_scale=0.3, **HP)
+    rep = smp.extract(vid.half().to(dev), noise.half().to(dev), text[[0]].half().to(dev))
+    noisy = smp.add_noise(400, vid.half(), noise.half()).float()
+    rec = {}
+    with torch.no_grad():
+        U.unet_forward(sd, cfg, noisy, 400, text[[0]].half().float(), only_motion_feature=True, record=rec)
+        prob = G.temp_attn_prob(rec, cfg["motion_heads"])
+    ref = G.motion_representation(prob)
+    assert list(rep) == list(ref)
+    for k in ref:
+        v, i = rep[k]
+        assert v.shape == ref[k][0].shape and i.dtype == torch.uint8
+        assert (v.float().cpu() - ref[k][0]).abs().max() < 5e-3
+        mism = i.cpu() != ref[k][1]
+        if mism.any():  # index flips only where the two best probabilities are within fp16 noise
+            p = prob[k]
+            alt = torch.gather(p, -1, i.cpu().long())
+            assert ((ref[k][0] - alt)[mism] < 5e-3).all()
+            assert mism.float().mean() < 0.02
+
+
+def test_guided_and_plain_step_match_oracle(backend, tiny):
+    dev = backend
+    cfg, sd = tiny
+    lat, text, vid, noise = make_inputs(cfg)
+    lat16, text16 = lat.half(), text.half()
+    N, Gs, gscale = 4, 2, 0.3
+    hp = dict(HP, guidance_steps=Gs)
+    rep = G.extract_representation(sd, cfg, vid, noise, text16[[0]].float())
+    ts = G.uneven_timesteps(N, Gs, gscale)
+    eng = UNet3DEngine(sd, cfg, dev)
+    smp = MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gscale, **HP)
+    assert smp.timesteps.tolist() == ts.tolist()
+    rep_dev = eng.prepare_representation(rep)
+
+    aux = {}
+    nxt = smp.step(lat16.to(dev), 0, text16.to(dev), rep_dev, aux=aux)
+    ref_nxt, ref_aux = G.guided_step(sd, cfg, lat16.float(), 0, ts, text16.float(), rep, hp)
+    assert rel_err(to_lat(aux["eps_c"], 1, 4, 8, 8), ref_aux["eps_c"]) < 2e-2
+    assert rel_err(to_lat(aux["eps_u"], 1, 4, 8, 8), ref_aux["eps_u"]) < 2e-2
+    assert abs(aux["loss"].item() - ref_aux["loss"].item()) < 3e-2 * abs(ref_aux["loss"].item())
+    g_err = rel_err(aux["grad"], ref_aux["grad"])
+    assert g_err < 5e-2, g_err
+    assert rel_err(nxt, ref_nxt) < 2e-2
+
+    aux2 = {}
+    p = smp.step(nxt, Gs, text16.to(dev), rep_dev, aux=aux2)
+    ref_p, _ = G.plain_step_full(sd, cfg, nxt.float().cpu(), Gs, ts, text16.float(), HP["cfg_scale"])
+    assert rel_err(p, ref_p) < 2e-2
+    last = smp.step(p, N - 1, text16.to(dev), rep_dev)
+    ref_last, _ = G.plain_step_full(sd, cfg, p.float().cpu(), N - 1, ts, text16.float(), HP["cfg_scale"])
+    assert rel_err(last, ref_last) < 2e-2
