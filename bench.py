@@ -1,0 +1,239 @@
+#!/usr/bin/env python
+"""Benchmark of the guided-DDIM hot path (BASELINE.json metric: videos/min + sec/denoise-step,
+16f x 512x512 SD1.5 + AnimateDiff, MotionClone guidance).
+
+A bench "step" is ONE VIDEO of BASELINE config 2: motion-representation extraction (partial UNet forward)
++ 30 DDIM steps of which the first 18 are guided (2 UNet forwards + guidance backward each) and 12 plain
+(one B=2 forward), schedule (N, G, guidance_scale) = (30, 18, 0.4) as in SURVEY.md 8(d); VAE/CLIP are
+outside the step metric and bypassed with synthetic tensors.  Synthetic random-init weights of the named
+architecture and synthetic latents / text embeddings (there are no checkpoints offline).
+
+Multi-GPU: replicas only - each rank samples its own (prompt, reference-video) pair; the only collective is
+one RCCL broadcast of the packed fp16 weights from rank 0 before the timed region.
+
+  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from motionclone_amd import lib, ops, spec  # noqa: E402
+from motionclone_amd.engine import UNet3DEngine, default_config  # noqa: E402
+from motionclone_amd.sampler import MotionCloneSampler  # noqa: E402
+
+# algorithmic work of the reference graph, FLOP = 2*MAC (measured on the reference's own code)
+TFLOP_GUIDED, TFLOP_PLAIN, TFLOP_EXTRACT = 45.50, 35.35, 10.06
+PEAK_FP16_MFMA_TFLOPS = 2500.0
+
+
+class GemmProbe:
+    """HIP-event timing of every launch of the dominant kernel (implicit-GEMM 3x3 conv, 128x128 tile) inside the
+    timed region.  The kernel is launched on torch's current stream, which is where the events are recorded."""
+
+    def __init__(self):
+        self.events = []
+        self.enabled = False
+        self._orig = ops.gemm
+
+    def install(self):
+        probe = self
+
+        def gemm(a, w, **kw):
+            mode = kw.get("mode", ops.DENSE)
+            if not probe.enabled or mode != ops.CONV_S1:
+                return probe._orig(a, w, **kw)
+            N, K = w.shape
+            M = kw["m_out"]
+            if ((M + 127) // 128) * ((N + 127) // 128) < 256:   # the C side picks the 64x64 tile
+                return probe._orig(a, w, **kw)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = probe._orig(a, w, **kw)
+            e1.record()
+            probe.events.append((e0, e1, 2.0 * M * N * K))
+            return out
+        ops.gemm = gemm
+
+    def summary(self):
+        if not self.events:
+            return None
+        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
+        fl = sum(f for _, _, f in self.events)
+        return dict(launches=len(self.events), avg_us=1e3 * ms / len(self.events), total_ms=ms,
+                    tflops=fl / ms / 1e9, flop_per_launch=fl / len(self.events))
+
+
+def synth_inputs(dev, F, H, W, seed):
+    """latents = prepare_latents(seed) (pipeline_animation.py:316), text ~ N(0,1) [2,77,768],
+    reference-video latents 0.18215 * N(0,1), extraction noise from the example seed."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    lat = torch.randn((1, 4, F, H // 8, W // 8), generator=g, device=dev, dtype=torch.float16)
+    text = torch.randn((2, 77, 768), generator=torch.Generator(device=dev).manual_seed(7), device=dev).half()
+    vid = (0.18215 * torch.randn((1, 4, F, H // 8, W // 8), generator=torch.Generator(device=dev).manual_seed(11),
+                                 device=dev)).half()
+    noise = torch.randn((1, 4, F, H // 8, W // 8), generator=torch.Generator(device=dev).manual_seed(seed),
+                        device=dev, dtype=torch.float16)
+    return lat, text, vid, noise
+
+
+def one_video(smp, lat, text, vid, noise, step_events=None):
+    rep = smp.extract(vid, noise, text[0:1], add_noise_step=400)
+    rep_dev = smp.engine.prepare_representation(rep)
+    x = lat
+    for i in range(len(smp.timesteps)):
+        if step_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        x = smp.step(x, i, text, rep_dev)
+        if step_events is not None:
+            e1.record()
+            step_events.append((i < smp.G, e0, e1))
+    return x
+
+
+def cpu_baseline():
+    """The oracle (CPU restatement of the reference path, oracle/unet3d_ref.py) timed on this box's host cores on a
+    bounded sample: one B=1 fp32 UNet3D forward of the full SD1.5+AnimateDiff architecture at 16f x 256x256
+    (4.087 TFLOP), scaled by algorithmic FLOPs to a config-2 video (1253 TFLOP)."""
+    from oracle import unet3d_ref as U
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = U.SD15_CONFIG
+    g = torch.Generator().manual_seed(1234)
+    sd = {}
+    for name, shape in U.param_shapes(cfg).items():  # cheap seeded fill (values do not affect the timing)
+        sd[name] = torch.randn(shape, generator=g) * 0.02 if len(shape) > 1 else torch.zeros(shape) + (
+            1.0 if name.endswith("weight") else 0.0)
+    lat = torch.randn(1, 4, 16, 32, 32, generator=g)
+    text = torch.randn(1, 77, 768, generator=g)
+    with torch.no_grad():
+        t0 = time.time()
+        U.unet_forward(sd, cfg, lat, 500, text)
+        dt = time.time() - t0
+    tflop_video = 18 * TFLOP_GUIDED + 12 * TFLOP_PLAIN + TFLOP_EXTRACT
+    sec_video = dt * tflop_video / 4.087
+    return dict(value=60.0 / sec_video, unit="videos/min", cores=cores, kind="port",
+                sample="oracle fp32 UNet3D forward, B=1, 16f x 256x256 (4.087 TFLOP) in %.1f s on %d threads; "
+                       "scaled by algorithmic FLOPs to one config-2 video (1253 TFLOP)" % (dt, cores),
+                sample_seconds=dt, tflops=4.087 / dt)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2, help="videos timed per GPU")
+    ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up videos per GPU")
+    ap.add_argument("--frames", type=int, default=16)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    lib.load()  # fails loudly if the gfx950 library is missing
+
+    cfg = default_config()
+    total = sum(int(torch.Size(s).numel()) for s in spec.param_shapes(cfg).values())
+    flat = torch.empty(total, dtype=torch.float16, device=dev)
+    if rank == 0:
+        sd, flat = spec.synthetic_state_dict(cfg, seed=1234, device=dev, flat=flat)
+    if world > 1:
+        dist.broadcast(flat, src=0)  # RCCL over xGMI: 2.38 GiB once, outside the timed region
+    if rank != 0:
+        sd, off = {}, 0
+        for name, shape in spec.param_shapes(cfg).items():
+            n = int(torch.Size(shape).numel())
+            sd[name] = flat[off:off + n].view(shape)
+            off += n
+    eng = UNet3DEngine(sd, cfg, dev)
+    N_STEPS, G_STEPS, G_SCALE = 30, 18, 0.4
+    smp = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
+                             num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE)
+    # per-rank example seeds as in configs/t2v_camera.jsonl (42, 42, 2026, default 2025, ...)
+    seeds = [42, 42, 2026, 2025, 2026, 2026, 2026, 2025]
+    lat, text, vid, noise = synth_inputs(dev, args.frames, args.size, args.size, seeds[rank % len(seeds)])
+
+    probe = GemmProbe()
+    probe.install()
+    for _ in range(args.warmup):
+        out = one_video(smp, lat, text, vid, noise)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    probe.enabled = True
+    step_events = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_video(smp, lat, text, vid, noise, step_events)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    probe.enabled = False
+    assert torch.isfinite(out.float()).all(), "non-finite latents"
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    if rank == 0:
+        gsec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if g]
+        psec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if not g]
+        videos = args.steps * world
+        tflop_video = G_STEPS * TFLOP_GUIDED + (N_STEPS - G_STEPS) * TFLOP_PLAIN + TFLOP_EXTRACT
+        ps = probe.summary()
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic_conv_gemm.json")
+        if os.path.exists(tfile):
+            traffic = json.load(open(tfile)).get("bytes_per_launch")
+        roof = None
+        if ps:
+            roof = dict(bound="mfma", kernel="gemm_kernel<CONV_S1,128,128> (implicit-GEMM 3x3 conv)",
+                        achieved=ps["tflops"], peak=PEAK_FP16_MFMA_TFLOPS, unit="TFLOP/s",
+                        frac=ps["tflops"] / PEAK_FP16_MFMA_TFLOPS, traffic=traffic, launches=ps["launches"],
+                        avg_launch_us=ps["avg_us"], flop_per_launch=ps["flop_per_launch"],
+                        share_of_timed_region=ps["total_ms"] / 1e3 / (elapsed / 1.0) if world == 1 else None)
+        res = {
+            "metric": "videos/min (16f x 512x512 SD1.5+AnimateDiff-v3 arch, 30-step DDIM, 18 guided, MotionClone guidance)",
+            "value": videos / (elapsed / 60.0), "unit": "videos/min", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE config 2: t2v_object-style sample, 16 frames, %dx%d, UNet only "
+                                   "(extraction + 18 guided + 12 plain DDIM steps), schedule (30,18,0.4)"
+                                   % (args.size, args.size),
+                       "videos_per_gpu": args.steps, "parallelism": "replicas x%d" % world},
+            "sec_per_guided_step": sum(gsec) / max(1, len(gsec)), "sec_per_plain_step": sum(psec) / max(1, len(psec)),
+            "sec_per_denoise_step": (sum(gsec) + sum(psec)) / max(1, len(gsec) + len(psec)),
+            "e2e_tflops_per_gpu": tflop_video * args.steps / elapsed,
+            "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        else:
+            res["cpu_baseline"] = None
+        print(json.dumps(res))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
