@@ -91,6 +91,9 @@ int mc_tattn_fwd_f16(const void* q, const void* k, const void* v, int ld, void* 
 /* motionclone_functions.py:260-283 + torch.topk(k=1) of :79 -> top_val fp16 / top_idx u8, [B*HW, heads, F] */
 int mc_tattn_top1_f16(const void* q, const void* k, int ld, void* top_val, void* top_idx, int B, int F, int HW,
                       int heads, int d, float scale, void* stream);
+/* get_temp_attn_prob (motionclone_functions.py:260-283): prob fp16 [B*HW, heads, F, F] */
+int mc_tattn_prob_f16(const void* q, const void* k, int ld, void* prob, int B, int F, int HW, int heads, int d,
+                      float scale, void* stream);
 /* motionclone_functions.py:85-100 for one module: loss[0] = mean((gather(P, idx) - ref)^2).
  * unit_loss: float[B*HW*heads] workspace. */
 int mc_tattn_loss_f16(const void* q, const void* k, int ld, const void* ref_idx, const float* ref_val,

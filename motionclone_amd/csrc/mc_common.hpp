@@ -16,6 +16,7 @@
 #include <stdint.h>
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 
 namespace mc {
 
@@ -29,6 +30,15 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int kWave = 64;
+
+#ifndef MC_EMU
+static thread_local int g_launch_error = 0;
+static inline void note_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    g_launch_error = (int)e;
+    if (e != hipSuccess) fprintf(stderr, "motionclone_hip: launch of %s failed: %s (%d)\n", what, hipGetErrorString(e), (int)e);
+}
+#endif
 
 #ifdef MC_EMU
 // ---- simulator lowering -------------------------------------------------------
@@ -65,9 +75,15 @@ __device__ __forceinline__ f32x16 mfma32(half8_t a, half8_t b, f32x16 c) {
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
 #define MC_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) char name[]
-#define MC_LAUNCH(kern, grid, block, smem, stream, ...) \
-    hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__)
-#define MC_LAST_ERROR() ((int)hipGetLastError())
+// hipGetLastError() is sticky per thread and PyTorch leaves benign errors behind: drop anything stale before a
+// launch, and report the launch's own status with its name.
+#define MC_LAUNCH(kern, grid, block, smem, stream, ...)                                   \
+    do {                                                                                  \
+        (void)hipGetLastError();                                                          \
+        hipLaunchKernelGGL(kern, (grid), (block), (smem), (stream), __VA_ARGS__);         \
+        mc::note_launch(#kern);                                                           \
+    } while (0)
+#define MC_LAST_ERROR() (mc::g_launch_error)
 // dynamic LDS above 64 KiB has to be opted into per kernel (gfx950 has 160 KiB per CU)
 template <class K>
 static inline void allow_big_smem(K kern, size_t bytes) {

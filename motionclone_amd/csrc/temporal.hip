@@ -178,6 +178,18 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
         float m, l;
         t_softmax_T<NT>(st, m, l);
         const float inv = 1.0f / l;
+        if (mode == 3) {  // full probabilities P[unit][q][kv] (fp16), as get_temp_attn_prob returns them
+            if (qf < P.F) {
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        int kv = 16 * tk + 4 * (lane >> 4) + i;
+                        if (kv < P.F) top_val[(unit * P.F + qf) * P.F + kv] = (half_t)(st[tk][i] * inv);
+                    }
+            }
+            continue;
+        }
         if (mode == 2) {
             int idx = qf < P.F ? (int)ref_idx[unit * P.F + qf] : 0;
             float pv = 0.f;
@@ -463,6 +475,20 @@ extern "C" int mc_tattn_top1_f16(const void* q, const void* k, int ld, void* top
     hipStream_t s = (hipStream_t)stream;
 #define CALL(NT_, DT_) \
     t_launch_fwd<NT_, DT_>(P, nullptr, 0, 1, (half_t*)top_val, (uint8_t*)top_idx, nullptr, nullptr, nullptr, s)
+    MC_T_DISPATCH(CALL)
+#undef CALL
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// motionclone_functions.py:260-283: prob fp16 [B*HW, heads, F, F]
+extern "C" int mc_tattn_prob_f16(const void* q, const void* k, int ld, void* prob, int B, int F, int HW, int heads,
+                                 int d, float scale, void* stream) {
+    TParams P = t_params(q, k, k, ld, B, F, HW, heads, d, scale);
+    if (!t_check(P)) return MC_ERR_SHAPE;
+    int nt = (F + 15) / 16, dt = (d + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(NT_, DT_) \
+    t_launch_fwd<NT_, DT_>(P, nullptr, 0, 3, (half_t*)prob, nullptr, nullptr, nullptr, nullptr, s)
     MC_T_DISPATCH(CALL)
 #undef CALL
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;

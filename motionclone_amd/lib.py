@@ -30,6 +30,7 @@ SIGNATURES = {
     "mc_attn_bwd_f16": [P, P, P, I, I, I, P, I, P, I, P, P, P, I, P, I, P, I, I, I, I, I, I, I, F, P],
     "mc_tattn_fwd_f16": [P, P, P, I, P, I, I, I, I, I, I, F, P],
     "mc_tattn_top1_f16": [P, P, I, P, P, I, I, I, I, I, F, P],
+    "mc_tattn_prob_f16": [P, P, I, P, I, I, I, I, I, F, P],
     "mc_tattn_loss_f16": [P, P, I, P, P, P, P, I, I, I, I, I, F, P],
     "mc_tattn_bwd_f16": [P, P, P, I, P, I, P, P, P, I, P, P, F, I, I, I, I, I, F, P],
     "mc_reduce_sum_f32": [P, L, F, P, P],

@@ -184,6 +184,14 @@ def tattn_top1(q, k, B, F, HW, heads, d, scale=None):
     return val, idx
 
 
+def tattn_prob(q, k, B, F, HW, heads, d, scale=None):
+    """-> P fp16 [B*HW, heads, F, F] (get_temp_attn_prob, motionclone_functions.py:260-283)"""
+    scale = d ** -0.5 if scale is None else scale
+    prob = empty((B * HW, heads, F, F), q)
+    lib.call("mc_tattn_prob_f16", _p(q), _p(k), _ld(q), _p(prob), B, F, HW, heads, d, float(scale), _stream(q))
+    return prob
+
+
 def tattn_loss(q, k, ref_idx, ref_val, B, F, HW, heads, d, scale=None):
     scale = d ** -0.5 if scale is None else scale
     assert ref_idx.dtype == torch.uint8 and ref_idx.is_contiguous()

@@ -251,6 +251,7 @@ def test_temporal_attention_and_guidance(backend, F_, d):
     ref = P @ V
     close(o, _temporal_unref(ref, B, F_, HW, heads, d), 1e-2, 1e-2, "tattn fwd")
 
+    close(ops.tattn_prob(q, k, B, F_, HW, heads, d), P, 2e-3, 2e-3, "tattn prob")
     # extraction: top-1 of P (motionclone_functions.py:79)
     val, idx = ops.tattn_top1(q, k, B, F_, HW, heads, d)
     rv, ri = torch.topk(P, 1, -1)
