@@ -1,0 +1,30 @@
+"""Minimal DDIM scheduler state for boxes without diffusers: exactly the attributes the path reads from
+`diffusers.DDIMScheduler`: alphas_cumprod, final_alpha_cumprod, init_noise_sigma, config,
+num_inference_steps, timesteps, scale_model_input, step signature (eta, generator)."""
+import types
+
+import torch
+
+from .sampler import ddim_alphas_cumprod
+
+
+class DDIMSchedulerState:
+    def __init__(self, num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="linear",
+                 steps_offset=1, clip_sample=False, set_alpha_to_one=True, prediction_type="epsilon", **unused):
+        if beta_schedule != "linear" or prediction_type != "epsilon" or clip_sample:
+            raise NotImplementedError("the path is configured with linear betas, epsilon prediction, no clipping "
+                                      "(configs/model_config/model_config.yaml:16-21)")
+        self.alphas_cumprod = ddim_alphas_cumprod(num_train_timesteps, beta_start, beta_end)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.init_noise_sigma = 1.0
+        self.num_inference_steps = None
+        self.timesteps = None
+        self.config = types.SimpleNamespace(num_train_timesteps=num_train_timesteps, steps_offset=steps_offset,
+                                            clip_sample=clip_sample, prediction_type=prediction_type,
+                                            thresholding=False)
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def step(self, model_output, timestep, sample, eta=0.0, generator=None):
+        raise NotImplementedError("use customized_step (schedule_customized_step) as the reference does")

@@ -1,0 +1,211 @@
+"""The MotionClone guidance layer with the reference's function names and signatures
+(reference motionclone/utils/motionclone_functions.py), to be bound onto pipeline / scheduler / unet with
+`fn.__get__(obj)` exactly as t2v_video_sample.py:57-65 does.  Arithmetic runs in the HIP engine
+(motionclone_amd/engine.py); these functions only orchestrate and keep the reference's quirks:
+CFG is eps_c + s (eps_c - eps_u) (:239,255); extraction uses the empty-prompt embedding at add_noise_step (:36-41);
+warm-up / cool-down factors (:228-234); x0 of the DDIM update uses the un-guided eps (:340,375-389)."""
+import os  # noqa: F401  (re-exported: the reference's entry scripts rely on `import *` providing these names)
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np  # noqa: F401
+import torch
+
+from .. import ops
+from ..sampler import MotionCloneSampler, uneven_timesteps
+from .conv_layer import prep_unet_conv  # noqa: F401
+from .util import classify_blocks, set_all_seed, video_preprocess  # noqa: F401
+from .xformer_attention import MySelfAttnProcessor, prep_unet_attention  # noqa: F401
+
+try:  # einops / imageio are re-exported by the reference module; keep the names when available
+    from einops import rearrange  # noqa: F401
+except ImportError:  # pragma: no cover
+    rearrange = None
+try:
+    import imageio  # noqa: F401
+except ImportError:  # pragma: no cover
+    imageio = None
+
+
+@dataclass
+class UNet3DConditionOutput:
+    sample: torch.Tensor
+
+
+def add_noise(self, timestep, x_0, noise_pred):
+    """:19-23"""
+    alpha_prod_t = self.scheduler.alphas_cumprod[timestep]
+    beta_prod_t = 1 - alpha_prod_t
+    return (alpha_prod_t ** 0.5 * x_0.float() + beta_prod_t ** 0.5 * noise_pred.float()).to(x_0.dtype)
+
+
+def _sampler(pipe):
+    """MotionCloneSampler over the pipeline's unet engine, configured from pipe.input_config (cached)."""
+    c = pipe.input_config
+    key = (id(pipe.unet.engine()), c.cfg_scale, c.motion_guidance_weight, c.warm_up_steps, c.cool_up_steps,
+           c.inference_steps, c.guidance_steps, c.guidance_scale)
+    if getattr(pipe, "_mc_sampler_key", None) != key:
+        pipe._mc_sampler = MotionCloneSampler(pipe.unet.engine(), cfg_scale=c.cfg_scale,
+                                              motion_guidance_weight=c.motion_guidance_weight,
+                                              warm_up_steps=c.warm_up_steps, cool_up_steps=c.cool_up_steps,
+                                              num_inference_steps=c.inference_steps, guidance_steps=c.guidance_steps,
+                                              guidance_scale=c.guidance_scale)
+        pipe._mc_sampler_key = key
+    return pipe._mc_sampler
+
+
+@torch.no_grad()
+def obtain_motion_representation(self, generator=None, motion_representation_path: str = None, duration=None,
+                                 use_controlnet=False, video_latents=None, uncond_embeddings=None):
+    """:25-82.  `video_latents` / `uncond_embeddings` let synthetic inputs bypass decord / VAE / CLIP."""
+    if use_controlnet:
+        raise NotImplementedError("SparseCtrl (i2v) is scheduled after the t2v path (SURVEY.md 8a A16)")
+    cfg = self.input_config
+    if video_latents is None:
+        video_data = video_preprocess(cfg.video_path, cfg.height, cfg.width, cfg.video_length, duration=duration)
+        lat = self.vae.encode(video_data.to(self.vae.dtype).to(self.vae.device)).latent_dist.sample(None)
+        video_latents = (self.vae.config.scaling_factor * lat).unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
+    if uncond_embeddings is None:
+        tok = self.tokenizer([""], padding="max_length", max_length=self.tokenizer.model_max_length, return_tensors="pt")
+        uncond_embeddings = self.text_encoder(tok.input_ids.to(self.device))[0]
+    step_t = int(cfg.add_noise_step)
+    noise = torch.randn(video_latents.shape, generator=generator, device=video_latents.device, dtype=video_latents.dtype)
+    noisy = self.add_noise(step_t, video_latents, noise)
+    # partial forward up to the guidance block; the hooked attentions record their q / k (:74-76)
+    self.unet(noisy.half(), step_t, encoder_hidden_states=uncond_embeddings.half(), return_dict=False,
+              only_motion_feature=True)
+    rep = {}
+    for name, module in self.unet.named_modules():
+        if "VersatileAttention" in type(module).__name__ and classify_blocks(cfg.motion_guidance_blocks, name):
+            r = module.processor.key
+            C, g = r["C"], r["geo"]
+            val, idx = ops.tattn_top1(r["qkv"][:, :C], r["qkv"][:, C:2 * C], g.B, g.F, g.hw, module.heads, r["d"])
+            rep[name] = [val, idx]   # topk(k=1) value / uint8 index (:79)
+    if motion_representation_path is not None:
+        # the reference's on-disk format: {module name: [values fp16 [BN, heads, F, 1], indices uint8 [...]]} (:79-81)
+        torch.save({k: [v.cpu(), i.cpu()] for k, (v, i) in rep.items()}, motion_representation_path)
+    self.motion_representation_path = motion_representation_path
+    self.motion_representation_dict = rep
+    return rep
+
+
+def get_temp_attn_prob(self, index_select=None):
+    """:260-283: P = softmax(scale q k^T) [(b n), heads, F, F] for every hooked temporal attention."""
+    if index_select is not None:
+        raise NotImplementedError("index_select is never passed on the reference path")
+    out = {}
+    for name, module in self.unet.named_modules():
+        if "VersatileAttention" in type(module).__name__ and classify_blocks(self.input_config.motion_guidance_blocks, name):
+            r = module.processor.key
+            C, g = r["C"], r["geo"]
+            out[name] = ops.tattn_prob(r["qkv"][:, :C], r["qkv"][:, C:2 * C], g.B, g.F, g.hw, module.heads, r["d"])
+    return out
+
+
+def compute_temp_loss(self, temp_attn_prob_control_dict):
+    """:85-100: sum over hooked modules of mse(gather(P, ref_idx), ref_val), evaluated by the fused HIP loss kernel
+    on the recorded q / k of each module (the dict argument supplies the module names)."""
+    total = None
+    for name in temp_attn_prob_control_dict.keys():
+        module = dict(self.unet.named_modules())[name]
+        r = module.processor.key
+        C, g = r["C"], r["geo"]
+        val, idx = self.motion_representation_dict[name]
+        dev = r["qkv"].device
+        lm = ops.tattn_loss(r["qkv"][:, :C], r["qkv"][:, C:2 * C], idx.to(dev, torch.uint8).contiguous(),
+                            val.to(dev, torch.float32).contiguous(), g.B, g.F, g.hw, module.heads, r["d"])
+        total = lm if total is None else total + lm
+    return total.reshape(())
+
+
+def single_step_video(self, noisy_latents, step_index, step_t, extra_step_kwargs):
+    """:173-257 (guided branch while step_index < guidance_steps, else one B=2 forward)"""
+    if getattr(self, "add_controlnet", False):
+        raise NotImplementedError("SparseCtrl (i2v) is scheduled after the t2v path (SURVEY.md 8a A16)")
+    smp = _sampler(self)
+    if getattr(self, "_mc_rep_src", None) is not self.motion_representation_dict:
+        self._mc_rep_dev = smp.engine.prepare_representation(self.motion_representation_dict)
+        self._mc_rep_src = self.motion_representation_dict
+    out = smp.step(noisy_latents.half(), step_index, self.text_embeddings.half(), self._mc_rep_dev)
+    return out.detach()
+
+
+def sample_video(self, eta: float = 0.0, generator=None, noisy_latents: Optional[torch.Tensor] = None,
+                 add_controlnet: bool = False, text_embeddings=None, decode=True):
+    """:102-171"""
+    self.add_controlnet = add_controlnet
+    if add_controlnet:
+        raise NotImplementedError("SparseCtrl (i2v) is scheduled after the t2v path (SURVEY.md 8a A16)")
+    cfg = self.input_config
+    device = self._execution_device
+    if text_embeddings is None:
+        text_embeddings = self._encode_prompt(cfg.new_prompt, device, 1, True, cfg.negative_prompt)
+    self.text_embeddings = text_embeddings
+    noisy_latents = self.prepare_latents(1, self.unet.config.in_channels, cfg.video_length, cfg.height, cfg.width,
+                                         self.text_embeddings.dtype, device, generator, noisy_latents)
+    if isinstance(getattr(self, "motion_representation_path", None), str) and os.path.exists(self.motion_representation_path):
+        self.motion_representation_dict = torch.load(self.motion_representation_path)
+    self.motion_scale = cfg.motion_guidance_weight
+    extra_step_kwargs = self.prepare_extra_step_kwargs(generator, eta)
+    with self.progress_bar(total=cfg.inference_steps) as progress_bar:
+        for step_index, step_t in enumerate(self.scheduler.timesteps):
+            noisy_latents = self.single_step_video(noisy_latents, step_index, step_t, extra_step_kwargs)
+            progress_bar.update()
+    if not decode:
+        return noisy_latents
+    return self.decode_latents(noisy_latents)
+
+
+@torch.no_grad()
+def schedule_customized_step(self, model_output, step_index: int, sample, eta: float = 0.0,
+                             use_clipped_model_output: bool = False, generator=None, variance_noise=None,
+                             return_dict: bool = True, score=None, guidance_scale=1.0, indices=None,
+                             return_middle=False):
+    """:285-409 for the configuration the path uses (epsilon prediction, eta = 0, no clipping): one fused kernel."""
+    if self.num_inference_steps is None:
+        raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+    if eta != 0.0 or use_clipped_model_output or indices is not None or return_middle:
+        raise NotImplementedError("only the eta = 0 DDIM update used by single_step_video is built")
+    t = int(self.timesteps[step_index])
+    t_prev = int(self.timesteps[step_index + 1]) if step_index + 1 < len(self.timesteps) else -1
+    a_t = float(self.alphas_cumprod[t])
+    a_prev = float(self.alphas_cumprod[t_prev]) if t_prev >= 0 else float(self.final_alpha_cumprod)
+    eps_cl = ops.latent_to_cl(model_output.half(), 8)
+    coef = float(guidance_scale) * (1.0 - a_t) ** 0.5 if (score is not None and guidance_scale > 0.0) else 0.0
+    prev, eps = ops.cfg_ddim_step(eps_cl, eps_cl, sample.half(), None if score is None else score.float(), 0.0, a_t,
+                                  a_prev, coef, want_eps=True)
+    if not return_dict:
+        return (prev,)
+    x0 = (sample.float() - (1 - a_t) ** 0.5 * model_output.float()) / a_t ** 0.5
+    return prev, x0.to(sample.dtype), a_prev
+
+
+def schedule_set_timesteps(self, num_inference_steps: int, guidance_steps: int = 0, guiduance_scale: float = 0.0,
+                           device=None, timestep_spacing_type="uneven"):
+    """:413-472"""
+    ntt = self.config.num_train_timesteps
+    if num_inference_steps > ntt:
+        raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than `self.config.train_timesteps`:"
+                         f" {ntt} as the unet model trained with this scheduler can only handle maximal {ntt} timesteps.")
+    self.num_inference_steps = num_inference_steps
+    if timestep_spacing_type == "uneven":
+        timesteps = uneven_timesteps(num_inference_steps, guidance_steps, guiduance_scale, ntt)
+    elif timestep_spacing_type == "linspace":
+        timesteps = np.linspace(0, ntt - 1, num_inference_steps).round()[::-1].copy().astype(np.int64)
+    elif timestep_spacing_type == "leading":
+        ratio = ntt // num_inference_steps
+        timesteps = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+    elif timestep_spacing_type == "trailing":
+        timesteps = np.round(np.arange(ntt, 0, -ntt / num_inference_steps)).astype(np.int64) - 1
+    else:
+        raise ValueError(f"{timestep_spacing_type} is not supported. Please make sure to choose one of 'leading' or 'trailing'.")
+    self.timesteps = torch.from_numpy(timesteps).to(device)
+
+
+def unet_customized_forward(self, sample, timestep, encoder_hidden_states, class_labels=None, attention_mask=None,
+                            down_block_additional_residuals=None, mid_block_additional_residual=None,
+                            return_dict: bool = True, only_motion_feature: bool = False):
+    """:478-662 - bound onto the unet by the entry script; delegates to the engine-backed forward."""
+    return type(self).forward(self, sample, timestep, encoder_hidden_states, class_labels, attention_mask,
+                              down_block_additional_residuals, mid_block_additional_residual, return_dict,
+                              only_motion_feature)

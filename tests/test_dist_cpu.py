@@ -1,0 +1,49 @@
+"""The N>1 path on CPU: two gloo ranks shard the example list, receive the packed weights with one broadcast and
+max-reduce their timings (replicas only, no data-path collective)."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+from motionclone_amd import dist as mcd
+from motionclone_amd import spec
+from oracle import unet3d_ref as U
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    r, w = mcd.init("gloo")
+    cfg = dict(U.TINY_CONFIG)
+    total = sum(int(torch.Size(s).numel()) for s in spec.param_shapes(cfg).values())
+    flat = torch.zeros(total, dtype=torch.float16)
+    if r == 0:
+        _, flat = spec.synthetic_state_dict(cfg, seed=1234, device="cpu", flat=flat)
+    mcd.broadcast_weights(flat, src=0)
+    lines = ["ex%d" % i for i in range(5)]
+    mine = mcd.shard_examples(lines, r, w)
+    t = mcd.max_over_ranks(1.0 + r)
+    path = mcd.representation_path("/tmp/mr", "reference_videos/camera_zoom_in.mp4", r, w)
+    out.put((r, float(flat.double().abs().sum()), [i for i, _ in mine], t, path))
+    torch.distributed.destroy_process_group()
+
+
+def test_two_rank_replicas_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (r0, sum0, ex0, t0, p0), (r1, sum1, ex1, t1, p1) = res
+    assert sum0 == sum1 and sum0 > 0          # rank 1 received rank 0's weights
+    assert ex0 == [0, 2, 4] and ex1 == [1, 3]  # round-robin sharding, every example exactly once
+    assert t0 == t1 == 2.0                     # max over ranks
+    assert p0 != p1                            # per-rank representation files
