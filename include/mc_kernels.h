@@ -39,10 +39,11 @@ int mc_version(void);
  * mode 4 TCONV_S2 : data-gradient of mode 2
  * A2 (optional) supplies channels [c1, ctot) - the skip concat of unet_blocks.py:634,740.
  * K = ctot (dense) or 9*ctot (conv; k = tap*ctot + c).  K, ctot, c1 multiples of 64; N, ldc multiples of 4.
- * tile: 0 = auto, 64 or 128 = block tile edge. */
+ * flags: bits 0-7 block tile edge (0 = auto, 64, 128); 0x100 = force the first-generation kernel;
+ *        0x200 = fused GEGLU epilogue: W rows interleaved (h_j, gate_j), C gets N/2 columns h_j * gelu(gate_j). */
 int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
-                int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int tile, void* stream);
+                int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
 
 /* ---- GroupNorm(32) [+SiLU] ------------------------------------------------------------------
  * resnet.py:21-29,186-187,197-203; attention.py:61,105; motion_module.py:112,145; unet.py:245.

@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
-SOURCES = ["gemm.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
+SOURCES = ["gemm.hip", "gemm2.hip", "gemm3.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
 HIP_LIB = os.path.join(CSRC, "libmotionclone_hip.so")
 EMU_DIR = os.path.join(REPO, "tests", "hipemu")
 EMU_LIB = os.path.join(EMU_DIR, "_build", "libmc_emu.so")
@@ -34,7 +34,7 @@ def _run(cmd):
 
 
 def _deps():
-    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "mc_common.hpp")]
+    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "mc_common.hpp"), os.path.join(CSRC, "gemm_params.hpp")]
 
 
 def build_hip(force=False, verbose=False):

@@ -19,35 +19,10 @@
 // LDS (16 B per lane, XOR-swizzled 16-byte slots: conflict-free ds_read_b128),
 // double-buffered, one barrier per K tile, next tile's global loads issued before
 // the current tile's MFMAs.
-#include "mc_common.hpp"
+#include "gemm_params.hpp"
 
 namespace mc {
 
-enum GemmMode { DENSE = 0, CONV_S1 = 1, CONV_S2 = 2, CONV_UP = 3, TCONV_S2 = 4 };
-
-struct GemmParams {
-    const half_t* A;
-    const half_t* A2;
-    const half_t* W;
-    half_t* C;
-    const half_t* R;
-    const float* bias;
-    int M, N, K;
-    int lda, lda2, ldc, ldr;
-    int c1;     // channels taken from A; the rest (ctot - c1) come from A2
-    int ctot;   // channels per tap (conv) or K (dense)
-    int Hs, Ws; // source grid (per frame)
-    int Ho, Wo; // output grid (per frame)
-    int rows_per_batch;
-    float alpha;
-};
-
-constexpr int BK = 64;
-
-__device__ __forceinline__ int lds_off(int row, int v) {
-    // byte offset of 16-byte slot v (0..7) of a 128-byte row; slots XOR-swizzled by (row>>1)&7
-    return row * 128 + ((v ^ ((row >> 1) & 7)) << 4);
-}
 
 template <int MODE, int BM, int BN>
 __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
@@ -249,6 +224,9 @@ static int launch_mode(const GemmParams& p, int small_tile, hipStream_t stream) 
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
+int gemm2_dispatch(const GemmParams& p, int mode, int small_tile, int deep, size_t rowsA, hipStream_t stream);
+int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStream_t stream);  // gemm3.hip  // gemm2.hip
+
 }  // namespace mc
 
 using namespace mc;
@@ -256,8 +234,14 @@ using namespace mc;
 extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
                            const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
                            int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
-                           int rows_per_batch, float alpha, int tile, void* stream) {
+                           int rows_per_batch, float alpha, int flags, void* stream) {
+    const int tile = flags & 0xFF;        // 0 = auto, 64, 128
+    const int force_v1 = flags & 0x100;   // first-generation kernel (register-staged operands)
+    const int epi = (flags & 0x200) ? 1 : 0;
+    const int deep = (flags & 0x400) ? 1 : 0;
+    int big_cfg = (flags >> 12) & 0xF;   // large-tile kernel geometry (gemm3.hip), 0 = choose automatically  // v2 with a 3-stage LDS ring (loads two K tiles ahead)  // fused GEGLU epilogue (weights row-interleaved h/gate)
     if (M <= 0 || N <= 0 || K <= 0) return MC_ERR_SHAPE;
+    if (epi && (R || N % 8 || force_v1)) return MC_ERR_UNSUPPORTED;
     if (K % BK || N % 4 || ldc % 4 || (R && (ldr % 4))) return MC_ERR_SHAPE;
     if (lda % 8 || (A2 && lda2 % 8)) return MC_ERR_SHAPE;
     if (mode < 0 || mode > 4) return MC_ERR_UNSUPPORTED;
@@ -274,7 +258,7 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
     p.C = (half_t*)C; p.R = (const half_t*)R; p.bias = bias;
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
     p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
-    p.rows_per_batch = rows_per_batch; p.alpha = alpha;
+    p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi;
     int small_tile = tile == 64;
     if (tile == 0) {
         // heuristic: fall to 64x64 tiles when 128x128 would leave most of the 256 CUs idle
@@ -282,6 +266,24 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
         small_tile = big < 256;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (!big_cfg && !tile && !force_v1 && !deep && N % 320 == 0) {
+        // measured on MI355X (profiles/r01_kernel_microbench_v3.jsonl): the 256x320 / 128x320 geometries win
+        // once they still fill the 256 CUs; smaller problems stay on the 128x128 / 64x64 tiles
+        long b1 = (long)((M + 255) / 256) * (N / 320), b4 = (long)((M + 127) / 128) * (N / 320);
+        if (b1 >= 224) big_cfg = 1;
+        else if (b4 >= 192) big_cfg = 4;
+    }
+    if (big_cfg) {
+        size_t rowsA3 = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
+        int rc3 = gemm3_dispatch(p, mode, big_cfg, rowsA3, s);
+        if (rc3 != MC_ERR_UNSUPPORTED) return rc3;
+    }
+    if (!force_v1) {
+        size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
+        int rc = gemm2_dispatch(p, mode, small_tile, deep, rowsA, s);
+        if (rc != MC_ERR_UNSUPPORTED) return rc;
+        if (epi) return MC_ERR_UNSUPPORTED;
+    }
     switch (mode) {
         case DENSE: return launch_mode<DENSE>(p, small_tile, s);
         case CONV_S1: return launch_mode<CONV_S1>(p, small_tile, s);

@@ -1,0 +1,302 @@
+// GEMM / implicit-conv kernel, large-tile generation (contract: gemm_params.hpp, same as gemm.hip / gemm2.hip).
+//
+// Why: on gfx950 every LDS-DMA instruction (buffer_load_dwordx4 ... lds, 1 KiB) costs on the order of 100 issue
+// cycles, so the staging cost per workgroup tile must be amortised over far more MFMA work than a 128x128 tile
+// with four waves offers.  Here a workgroup is 8 waves (NWM x NWN), each owning a (32*TM) x (32*TN) block of
+// v_mfma_f32_32x32x16_f16 tiles; the block tile is BM x BN with BN a multiple of 320 where the layer widths of the
+// SD-1.5 UNet (320, 640, 960, 1280, 1920, 2560, ...) allow it, so no N padding is computed.
+// Everything else is as in gemm2.hip: operand tiles global -> LDS directly with the XOR swizzle on the source
+// address, hardware zero fill for conv padding / tails, XCD-aware tile order, accumulators leave through an LDS
+// staging tile as coalesced 16-byte row segments with the bias / residual / alpha / fused-GEGLU epilogue.
+#include "gemm_params.hpp"
+
+namespace mc {
+
+template <int MODE, int BM, int BN, int NWM, int NWN>
+__global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
+                                                                uint32_t bytesW, int tilesM, int tilesN) {
+    constexpr int NW = NWM * NWN;
+    constexpr int NT = 64 * NW;
+    constexpr int TM = BM / NWM / 32;
+    constexpr int TN = BN / NWN / 32;
+    constexpr int RA = BM / 8 / NW;  // 8-row groups staged per wave
+    constexpr int RW = BN / 8 / NW;
+    constexpr int WROWS = BM / NWM;  // rows of one wave-row = rows of one epilogue pass
+    constexpr int CS = BN + 4;
+    static_assert(BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile");
+    static_assert(NW % 2 == 0, "swizzle constant assumes an even wave count");
+    MC_DYN_SMEM(smem);
+    char* sA = smem;                  // [2][BM][128 B]
+    char* sW = smem + 2 * BM * 128;   // [2][BN][128 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int pid = blockIdx.x;
+    const int xcd = pid & 7, local = pid >> 3;
+    const int tn = local % tilesN;
+    const int tm = (local / tilesN) * 8 + xcd;
+    if (tm >= tilesM) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const GBuf bufA = make_gbuf(p.A, bytesA);
+    const GBuf bufA2 = make_gbuf(p.A2 ? p.A2 : p.A, p.A2 ? bytesA2 : bytesA);
+    const GBuf bufW = make_gbuf(p.W, bytesW);
+
+    const int rsub = lane >> 3;
+    const int sw = (((wave & 1) << 2) | (lane >> 4)) & 7;
+    const int lslot = (lane & 7) ^ sw;
+
+    int a_valid[RA], a_pix[RA], a_oy[RA], a_ox[RA];
+#pragma unroll
+    for (int i = 0; i < RA; ++i) {
+        int m = m0 + (wave + NW * i) * 8 + rsub;
+        a_valid[i] = m < p.M;
+        if (MODE == DENSE) {
+            a_pix[i] = m;
+            a_oy[i] = a_ox[i] = 0;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int fr = m / hw;
+            int rem = m - fr * hw;
+            int oy = rem / p.Wo;
+            a_pix[i] = fr * p.Hs * p.Ws;
+            a_oy[i] = oy;
+            a_ox[i] = rem - oy * p.Wo;
+        }
+    }
+    uint32_t w_off[RW];
+#pragma unroll
+    for (int i = 0; i < RW; ++i) {
+        int n = n0 + (wave + NW * i) * 8 + rsub;
+        w_off[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)lslot * 16u : kOOB;
+    }
+
+    auto issue_tiles = [&](int kt, int buf) {
+        const int k0 = kt * BK;
+        int tap = 0, c0 = k0;
+        if (MODE != DENSE) {
+            tap = k0 / p.ctot;
+            c0 = k0 - tap * p.ctot;
+        }
+        const bool second = c0 >= p.c1;
+        const int ld = second ? p.lda2 : p.lda;
+        const int cc = (second ? c0 - p.c1 : c0) + lslot * 8;
+        const int ky = tap / 3, kx = tap - 3 * (tap / 3);
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            bool ok = a_valid[i];
+            int row;
+            if (MODE == DENSE) {
+                row = a_pix[i];
+            } else {
+                int iy, ix;
+                if (MODE == CONV_S1) {
+                    iy = a_oy[i] + ky - 1;
+                    ix = a_ox[i] + kx - 1;
+                    ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                } else if (MODE == CONV_S2) {
+                    iy = 2 * a_oy[i] + ky - 1;
+                    ix = 2 * a_ox[i] + kx - 1;
+                    ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                } else if (MODE == CONV_UP) {
+                    int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
+                    ok = ok && uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                    iy = uy >> 1;
+                    ix = ux >> 1;
+                } else {
+                    int ty = a_oy[i] + 1 - ky, tx = a_ox[i] + 1 - kx;
+                    ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
+                    iy = ty >> 1;
+                    ix = tx >> 1;
+                    ok = ok && iy < p.Hs && ix < p.Ws;
+                }
+                row = a_pix[i] + iy * p.Ws + ix;
+            }
+            uint32_t voff = ok ? ((uint32_t)row * (uint32_t)ld + (uint32_t)cc) * 2u : kOOB;
+            char* dst = sA + buf * BM * 128 + (wave + NW * i) * 1024;
+            if (second)
+                glds16(bufA2, voff, dst);
+            else
+                glds16(bufA, voff, dst);
+        }
+#pragma unroll
+        for (int i = 0; i < RW; ++i) {
+            uint32_t voff = w_off[i] == kOOB ? kOOB : w_off[i] + (uint32_t)k0 * 2u;
+            glds16(bufW, voff, sW + buf * BN * 128 + (wave + NW * i) * 1024);
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wr = wave % NWM, wc = wave / NWM;
+    const int wm0 = wr * (32 * TM);
+    const int wn0 = wc * (32 * TN);
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int nk = p.K / BK;
+    issue_tiles(0, 0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) issue_tiles(kt + 1, buf ^ 1);
+        const char* bA = sA + buf * BM * 128;
+        const char* bW = sW + buf * BN * 128;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            half8_t fa[TM], fw[TN];
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                fa[j] = *reinterpret_cast<const half8_t*>(bA + lds_off(wm0 + 32 * j + l31, 2 * ks + lhi));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                fw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off(wn0 + 32 * i + l31, 2 * ks + lhi));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(fw[i], fa[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: one wave-row (WROWS rows x BN columns) at a time through an fp32 LDS staging tile ----
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int TPR = BN / 8;
+    constexpr int RPP = NT / TPR;       // rows per pass (threads beyond RPP*TPR idle in the store phase)
+    const int col = (tid % TPR) * 8;
+    const int n = n0 + col;
+    const bool vec16 = !(p.N & 7) && !(p.ldc & 7) && (!p.R || !(p.ldr & 7));
+#pragma unroll 1
+    for (int pass = 0; pass < NWM; ++pass) {
+        if (wr == pass) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        f32x4 v;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                        *reinterpret_cast<f32x4*>(Cs + (32 * j + l31) * CS + wn0 + 32 * i + 8 * q + 4 * lhi) = v;
+                    }
+        }
+        __syncthreads();
+        if (tid < RPP * TPR && n < p.N) {
+#pragma unroll 1
+            for (int r0 = 0; r0 < WROWS; r0 += RPP) {
+                const int rl = r0 + tid / TPR;
+                const int m = m0 + pass * WROWS + rl;
+                if (rl >= WROWS || m >= p.M) continue;
+                float v[8];
+                {
+                    f32x4 a = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col);
+                    f32x4 b = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = a[e];
+                        v[4 + e] = b[e];
+                    }
+                }
+                const int nvalid = min(8, p.N - n);
+                if (p.bias) {
+                    const float* brow = p.bias + (size_t)(m / p.rows_per_batch) * p.N + n;
+                    f32x4 b0 = *reinterpret_cast<const f32x4*>(brow);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b0[e];
+                    if (nvalid == 8) {
+                        f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[4 + e] += b1[e];
+                    }
+                }
+                if (p.epi == 1) {
+                    half4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[2 * e] * gelu_f(v[2 * e + 1]));
+                    half_t* dst = p.C + (size_t)m * p.ldc + (n >> 1);
+                    if (nvalid == 8) {
+                        st4(dst, o);
+                    } else {
+                        dst[0] = o[0];
+                        dst[1] = o[1];
+                    }
+                    continue;
+                }
+                if (vec16) {
+                    if (p.R) {
+                        half8_t r = ld8(p.R + (size_t)m * p.ldr + n);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
+                    }
+                    half8_t o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                    st8(p.C + (size_t)m * p.ldc + n, o);
+                } else {
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        if (4 * h >= nvalid) break;
+                        half4_t o;
+                        if (p.R) {
+                            half4_t r = ld4(p.R + (size_t)m * p.ldr + n + 4 * h);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) v[4 * h + e] += (float)r[e];
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[e] = to_half(v[4 * h + e]);
+                        st4(p.C + (size_t)m * p.ldc + n + 4 * h, o);
+                    }
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+template <int MODE, int BM, int BN, int NWM, int NWN>
+static int launch3(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
+    int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
+    size_t operands = (size_t)2 * (BM + BN) * 128;
+    size_t staging = (size_t)(BM / NWM) * (BN + 4) * 4;
+    size_t smem = operands > staging ? operands : staging;
+    allow_big_smem(gemm3_kernel<MODE, BM, BN, NWM, NWN>, smem);
+    dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN));
+    MC_LAUNCH((gemm3_kernel<MODE, BM, BN, NWM, NWN>), grid, dim3(64 * NWM * NWN), smem, stream, p, bA, bA2, bW, tM, tN);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+template <int MODE>
+static int launch3_cfg(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, int cfg, hipStream_t s) {
+    switch (cfg) {
+        case 1: return launch3<MODE, 256, 320, 4, 2>(p, bA, bA2, bW, s);   // wave 64 x 160
+        case 2: return launch3<MODE, 256, 256, 4, 2>(p, bA, bA2, bW, s);   // wave 64 x 128
+        case 3: return launch3<MODE, 256, 128, 4, 2>(p, bA, bA2, bW, s);   // wave 64 x 64
+        case 4: return launch3<MODE, 128, 320, 2, 2>(p, bA, bA2, bW, s);   // 4 waves, wave 64 x 160
+        case 5: return launch3<MODE, 128, 256, 2, 4>(p, bA, bA2, bW, s);   // wave 64 x 64
+        default: return MC_ERR_UNSUPPORTED;
+    }
+}
+
+// cfg: see launch3_cfg.  Returns MC_ERR_UNSUPPORTED when an operand does not fit a 2 GiB buffer descriptor.
+int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStream_t stream) {
+    size_t bytesA = (rowsA * (size_t)p.lda) * 2, bytesA2 = p.A2 ? (rowsA * (size_t)p.lda2) * 2 : 0;
+    size_t bytesW = (size_t)p.N * p.K * 2;
+    const size_t lim = 0x7FFFFFF0u;
+    if (bytesA > lim || bytesA2 > lim || bytesW > lim) return MC_ERR_UNSUPPORTED;
+    switch (mode) {
+        case DENSE: return launch3_cfg<DENSE>(p, bytesA, bytesA2, bytesW, cfg, stream);
+        case CONV_S1: return launch3_cfg<CONV_S1>(p, bytesA, bytesA2, bytesW, cfg, stream);
+        case CONV_S2: return launch3_cfg<CONV_S2>(p, bytesA, bytesA2, bytesW, cfg, stream);
+        case CONV_UP: return launch3_cfg<CONV_UP>(p, bytesA, bytesA2, bytesW, cfg, stream);
+        default: return launch3_cfg<TCONV_S2>(p, bytesA, bytesA2, bytesW, cfg, stream);
+    }
+}
+
+}  // namespace mc

@@ -1,0 +1,34 @@
+// Shared parameter block of the GEMM / implicit-conv kernels (gemm.hip, gemm2.hip).
+#pragma once
+#include "mc_common.hpp"
+
+namespace mc {
+
+enum GemmMode { DENSE = 0, CONV_S1 = 1, CONV_S2 = 2, CONV_UP = 3, TCONV_S2 = 4 };
+
+struct GemmParams {
+    const half_t* A;
+    const half_t* A2;
+    const half_t* W;
+    half_t* C;
+    const half_t* R;
+    const float* bias;
+    int M, N, K;
+    int lda, lda2, ldc, ldr;
+    int c1;     // channels taken from A; the rest (ctot - c1) come from A2
+    int ctot;   // channels per tap (conv) or K (dense)
+    int Hs, Ws; // source grid (per frame)
+    int Ho, Wo; // output grid (per frame)
+    int rows_per_batch;
+    float alpha;
+    int epi;    // 0: bias/residual epilogue, 1: fused GEGLU (v2 kernel only)
+};
+
+constexpr int BK = 64;
+
+__device__ __forceinline__ int lds_off(int row, int v) {
+    // byte offset of 16-byte slot v (0..7) of a 128-byte row; slots XOR-swizzled by (row>>1)&7
+    return row * 128 + ((v ^ ((row >> 1) & 7)) << 4);
+}
+
+}  // namespace mc

@@ -93,6 +93,55 @@ static inline void allow_big_smem(K kern, size_t bytes) {
 }
 #endif
 
+// ---- direct global -> LDS loads (LDS-DMA) ---------------------------------------------------------
+// glds16(buf, voff, lds): every lane moves 16 bytes from byte offset `voff` of the buffer straight into LDS at
+// (wave-uniform) `lds` + lane*16, without passing through VGPRs (buffer_load_dwordx4 ... lds).  An offset at or
+// beyond the buffer's size reads as zeros - that is how conv padding and M/N tails are filled, in hardware.
+// The data is visible to other waves after the issuing wave's vmcnt wait plus a workgroup barrier
+// (__syncthreads() provides both).
+#ifdef MC_EMU
+struct GBuf {
+    const char* base;
+    uint32_t bytes;
+};
+__device__ inline GBuf make_gbuf(const void* p, uint32_t bytes) { return GBuf{(const char*)p, bytes}; }
+__device__ inline void glds16(GBuf b, uint32_t voff, char* lds_wave_base) {
+    char* d = lds_wave_base + hipemu::lane_id() * 16;
+    if ((uint64_t)voff + 16 <= b.bytes)
+        memcpy(d, b.base + voff, 16);
+    else
+        memset(d, 0, 16);
+}
+#else
+typedef __amdgpu_buffer_rsrc_t GBuf;
+__device__ __forceinline__ GBuf make_gbuf(const void* p, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void glds16(GBuf b, uint32_t voff, char* lds_wave_base) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
+                                             (int)voff, 0, 0, 0);
+}
+#endif
+// counted wait on this wave's outstanding vector-memory operations, and a bare workgroup barrier (no fence)
+#ifdef MC_EMU
+template <int N>
+__device__ inline void wait_vmcnt_le() {}
+__device__ inline void raw_barrier() { __syncthreads(); }
+#else
+template <int N>
+__device__ __forceinline__ void wait_vmcnt_le() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+__device__ __forceinline__ void raw_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+}
+#endif
+// A voffset beyond every buffer we describe (callers keep buffers <= 2 GiB): forces the zero fill without any
+// 32-bit wrap in the range check.
+constexpr uint32_t kOOB = 0x80000000u;
+
 // reductions across the 64 lanes of a wave
 __device__ inline float wave_sum(float v) {
 #pragma unroll

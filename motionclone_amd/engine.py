@@ -120,6 +120,13 @@ class Weights:
             return self._h(w)
         return self._get(("conv_d", name, stride, pad_cin), mk)
 
+    def geglu_lin(self, name):
+        """FeedForward's first Linear with rows interleaved (h_j, gate_j) for the fused GEGLU epilogue"""
+        return self._get(("geglu_w", name), lambda: self._h(ops.interleave_geglu(self.sd[name])))
+
+    def geglu_vec(self, name):
+        return self._get(("geglu_b", name), lambda: self._f(ops.interleave_geglu(self.sd[name])).unsqueeze(0))
+
     def pe(self, dim):
         return self._get(("pe", dim), lambda: self._f(_pe_table(self.cfg["motion_pe_max_len"], dim)))
 
@@ -282,9 +289,13 @@ class UNet3DEngine:
                       residual=h1)
         # GEGLU feed-forward
         n3, ls3 = ops.layernorm_fwd(h2, w.vec(b + "norm3.weight"), w.vec(b + "norm3.bias"), save_stats=tape is not None)
-        ff1 = ops.gemm(n3, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
+        if tape is None:   # no backward: h * gelu(gate) is formed in the GEMM epilogue, the [T, 8C] tensor never exists
+            ff1 = None
+            gg = ops.gemm(n3, w.geglu_lin(b + "ff.net.0.proj.weight"), bias=w.geglu_vec(b + "ff.net.0.proj.bias"), geglu=True)
+        else:
+            ff1 = ops.gemm(n3, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
+            gg = ops.geglu_fwd(ff1)
         del n3
-        gg = ops.geglu_fwd(ff1)
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
         out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)
@@ -350,9 +361,13 @@ class UNet3DEngine:
             h = hnext
         h2 = h
         n, lsf = ops.layernorm_fwd(h2, w.vec(b + "ff_norm.weight"), w.vec(b + "ff_norm.bias"), save_stats=tape is not None)
-        ff1 = ops.gemm(n, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
+        if tape is None:
+            ff1 = None
+            gg = ops.gemm(n, w.geglu_lin(b + "ff.net.0.proj.weight"), bias=w.geglu_vec(b + "ff.net.0.proj.bias"), geglu=True)
+        else:
+            ff1 = ops.gemm(n, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
+            gg = ops.geglu_fwd(ff1)
         del n
-        gg = ops.geglu_fwd(ff1)
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
         out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)

@@ -47,10 +47,11 @@ def empty(shape, like, dtype=torch.float16):
 
 # ---- GEMM family ---------------------------------------------------------------------------------
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
-         rows_per_batch=0, tile=0, m_out=None):
+         rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
 
-    geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes."""
+    geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
+    geglu=True: w rows interleaved (h_j, gate_j) (see `interleave_geglu`), out gets N/2 columns h*gelu(gate)."""
     _f16(a), _f16(w)
     N, K = w.shape
     c1 = a.shape[1]
@@ -63,16 +64,24 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         Hs, Ws, Ho, Wo = geom
         M = m_out
         assert K == 9 * ctot, (K, ctot)
+    n_out = N // 2 if geglu else N
     if out is None:
-        out = empty((M, N), a)
-    assert out.shape[0] == M and out.shape[1] == N
+        out = empty((M, n_out), a)
+    assert out.shape[0] == M and out.shape[1] == n_out
+    flags = tile | (0x100 if v1 else 0) | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12)
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N
     lib.call("mc_gemm_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a), _ld(a2),
-             _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha), tile,
+             _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha), flags,
              _stream(a))
     return out
+
+
+def interleave_geglu(t):
+    """rows [h_0..h_{D-1}, g_0..g_{D-1}] -> [h_0, g_0, h_1, g_1, ...] (weight [2D, K] or bias [2D])"""
+    D = t.shape[0] // 2
+    return torch.stack([t[:D], t[D:]], dim=1).reshape(t.shape).contiguous()
 
 
 # ---- GroupNorm -------------------------------------------------------------------------------------

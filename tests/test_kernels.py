@@ -33,8 +33,57 @@ def close(a, b, atol, rtol, what=""):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.mark.parametrize("M,N,K,tile", [(200, 72, 128, 64), (300, 136, 192, 128), (77, 64, 64, 0)])
-def test_gemm_dense(backend, M, N, K, tile):
+@pytest.fixture(params=[False, True], ids=["v2", "v1"])
+def v1(request):
+    return request.param
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_gemm_large_tile_geometries(backend, cfg):
+    """gemm3.hip: every block geometry, dense with bias/residual/tails, conv with concat, fused GEGLU"""
+    dev = backend
+    M, N, K = (300, 328, 128) if not big(dev) else (3000, 968, 320)
+    a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+    bias = torch.randn(1, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = rnd((M, N), dev, 4)
+    out = ops.gemm(a, w, bias=bias, residual=res, alpha=0.5, cfg=cfg)
+    close(out, 0.5 * (a.float() @ w.float().t()) + bias + res.float(), 2e-2, 5e-3, "gemm3 dense")
+    NF, Cin, Cout, H, W = (2, 64, 72, 6, 10) if not big(dev) else (4, 128, 320, 24, 20)
+    x, x2 = rnd((NF, Cin, H, W), dev, 5), rnd((NF, 64, H, W), dev, 6)
+    wc = rnd((Cout, Cin + 64, 3, 3), dev, 7, 0.05)
+    o = ops.gemm(_to_cl(x), _conv_w_pack(wc), a2=_to_cl(x2), mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, cfg=cfg)
+    close(_from_cl(o, NF, H, W), Fn.conv2d(torch.cat([x, x2], 1).float(), wc.float(), padding=1), 3e-2, 5e-3, "gemm3 conv")
+    D = 80
+    wg = rnd((2 * D, K), dev, 8, 0.1)
+    y = a.float() @ wg.float().t()
+    og = ops.gemm(a, ops.interleave_geglu(wg), geglu=True, cfg=cfg)
+    close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm3 geglu")
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(300, 136, 64, 128), (300, 136, 128, 128), (333, 200, 448, 128), (200, 72, 320, 64)])
+def test_gemm_deep_pipeline(backend, M, N, K, tile):
+    """3-stage LDS ring variant (counted vmcnt): K of 1, 2 and many tiles"""
+    dev = backend
+    a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+    res = rnd((M, N), dev, 4)
+    out = ops.gemm(a, w, residual=res, tile=tile, deep=True)
+    close(out, a.float() @ w.float().t() + res.float(), 2e-2, 5e-3, "gemm deep")
+
+
+def test_gemm_geglu_epilogue(backend):
+    dev = backend
+    M, D, K = (150, 72, 128) if not big(dev) else (4099, 1280, 320)
+    a, w = rnd((M, K), dev, 1), rnd((2 * D, K), dev, 2, 0.1)
+    bias = torch.randn(2 * D, generator=torch.Generator().manual_seed(3)).to(dev)
+    y = a.float() @ w.float().t() + bias
+    ref = y[:, :D] * Fn.gelu(y[:, D:])
+    for tile in (64, 128):
+        out = ops.gemm(a, ops.interleave_geglu(w), bias=ops.interleave_geglu(bias).unsqueeze(0), geglu=True, tile=tile)
+        close(out, ref, 2e-2, 1e-2, "gemm+geglu tile %d" % tile)
+
+
+@pytest.mark.parametrize("M,N,K,tile", [(200, 72, 128, 64), (300, 136, 192, 128), (77, 64, 64, 0), (1100, 260, 320, 128)])
+def test_gemm_dense(backend, M, N, K, tile, v1):
     dev = backend
     if big(dev):
         M, N, K = M * 8 + 5, N * 4, K * 4
@@ -42,21 +91,21 @@ def test_gemm_dense(backend, M, N, K, tile):
     bias = torch.randn(2, N, generator=torch.Generator().manual_seed(3)).to(dev)
     res = rnd((M, N), dev, 4)
     rpb = (M + 1) // 2
-    out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=rpb, alpha=0.5, tile=tile)
+    out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=rpb, alpha=0.5, tile=tile, v1=v1)
     b_idx = (torch.arange(M, device=dev) // rpb)
     ref = 0.5 * (a.float() @ w.float().t()) + bias[b_idx] + res.float()
     close(out, ref, 2e-2, 5e-3, "gemm")
     # asymmetric operands would expose a transposed C-write; also check no-epilogue path
-    out2 = ops.gemm(a, w, tile=tile)
+    out2 = ops.gemm(a, w, tile=tile, v1=v1)
     close(out2, a.float() @ w.float().t(), 2e-2, 5e-3, "gemm plain")
 
 
-def test_gemm_concat_and_strided_out(backend):
+def test_gemm_concat_and_strided_out(backend, v1):
     dev = backend
     M, C1, C2, N = 130, 64, 128, 96
     a, a2, w = rnd((M, C1), dev, 1), rnd((M, C2), dev, 2), rnd((N, C1 + C2), dev, 3, 0.1)
     wide = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
-    ops.gemm(a, w, a2=a2, out=wide[:, N:2 * N])
+    ops.gemm(a, w, a2=a2, out=wide[:, N:2 * N], v1=v1)
     ref = torch.cat([a, a2], 1).float() @ w.float().t()
     close(wide[:, N:2 * N], ref, 2e-2, 5e-3, "gemm concat")
     assert wide[:, :N].abs().max() == 0 and wide[:, 2 * N:].abs().max() == 0
@@ -75,7 +124,7 @@ def _from_cl(x, NF, H, W):
 
 
 @pytest.mark.parametrize("mode", ["s1", "s2", "up", "concat"])
-def test_conv3x3(backend, mode):
+def test_conv3x3(backend, mode, v1):
     dev = backend
     NF, Cin, Cout, H, W = (3, 64, 72, 6, 10) if not big(dev) else (5, 192, 200, 24, 20)
     x = rnd((NF, Cin, H, W), dev, 1)
@@ -84,29 +133,29 @@ def test_conv3x3(backend, mode):
     xc = _to_cl(x)
     wp = _conv_w_pack(w)
     if mode == "s1":
-        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
+        out = ops.gemm(xc, wp, bias=bias, v1=v1, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
         ref = Fn.conv2d(x.float(), w.float(), bias[0], padding=1)
         Ho, Wo = H, W
     elif mode == "s2":
         Ho, Wo = H // 2, W // 2
-        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_S2, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
+        out = ops.gemm(xc, wp, bias=bias, v1=v1, mode=ops.CONV_S2, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
         ref = Fn.conv2d(x.float(), w.float(), bias[0], padding=1, stride=2)
     elif mode == "up":
         Ho, Wo = 2 * H, 2 * W
-        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_UP, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
+        out = ops.gemm(xc, wp, bias=bias, v1=v1, mode=ops.CONV_UP, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
         ref = Fn.conv2d(Fn.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias[0], padding=1)
     else:
         x2 = rnd((NF, 128, H, W), dev, 5)
         w = rnd((Cout, Cin + 128, 3, 3), dev, 6, 0.05)
         out = ops.gemm(xc, _conv_w_pack(w), a2=_to_cl(x2), bias=bias, mode=ops.CONV_S1, geom=(H, W, H, W),
-                       m_out=NF * H * W)
+                       m_out=NF * H * W, v1=v1)
         ref = Fn.conv2d(torch.cat([x, x2], 1).float(), w.float(), bias[0], padding=1)
         Ho, Wo = H, W
     close(_from_cl(out, NF, Ho, Wo), ref, 3e-2, 5e-3, "conv " + mode)
 
 
 @pytest.mark.parametrize("stride", [1, 2])
-def test_conv3x3_dgrad(backend, stride):
+def test_conv3x3_dgrad(backend, stride, v1):
     """data-gradient of the 3x3 conv = the same kernel with re-packed weights (autograd is the reference)."""
     dev = backend
     NF, Cin, Cout, H, W = (2, 64, 64, 8, 6) if not big(dev) else (4, 128, 192, 16, 24)
@@ -118,10 +167,10 @@ def test_conv3x3_dgrad(backend, stride):
     Ho, Wo = y.shape[2:]
     if stride == 1:
         wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
-        out = ops.gemm(_to_cl(dy), wd, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
+        out = ops.gemm(_to_cl(dy), wd, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, v1=v1)
     else:
         wd = w.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
-        out = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(Ho, Wo, H, W), m_out=NF * H * W)
+        out = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(Ho, Wo, H, W), m_out=NF * H * W, v1=v1)
     close(_from_cl(out, NF, H, W), ref, 3e-2, 5e-3, "conv dgrad s%d" % stride)
 
 

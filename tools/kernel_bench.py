@@ -35,17 +35,29 @@ for (name, H, Cin, Cout) in [("conv_l0", 64, 320, 320), ("conv_l1", 32, 640, 640
     x = r(F * H * H, Cin)
     w = r(Cout, 9 * Cin, s=0.02)
     for tile in (128, 64):
-        ms = timeit(lambda: ops.gemm(x, w, mode=ops.CONV_S1, geom=(H, H, H, H), m_out=F * H * H, tile=tile))
-        fl = 2.0 * F * H * H * Cout * 9 * Cin
-        out.append(dict(k=name, tile=tile, ms=ms, tflops=fl / ms / 1e9))
-for (name, M, N, K) in [("lin_qkv_l0", 65536, 960, 320), ("lin_ff1_l0", 65536, 2560, 320), ("lin_ff2_l0", 65536, 320, 1280),
+        for v in ("v1", "v2", "v3"):
+            ms = timeit(lambda: ops.gemm(x, w, mode=ops.CONV_S1, geom=(H, H, H, H), m_out=F * H * H, tile=tile,
+                                         v1=v == "v1", deep=v == "v3"))
+            fl = 2.0 * F * H * H * Cout * 9 * Cin
+            out.append(dict(k=name, tile=tile, v=v, ms=ms, tflops=fl / ms / 1e9))
+    for cfg in (1, 2, 3, 4, 5):
+        ms = timeit(lambda: ops.gemm(x, w, mode=ops.CONV_S1, geom=(H, H, H, H), m_out=F * H * H, cfg=cfg))
+        out.append(dict(k=name, tile=0, v="g3c%d" % cfg, ms=ms, tflops=2.0 * F * H * H * Cout * 9 * Cin / ms / 1e9))
+for (name, M, N, K) in [("lin_o_l0", 65536, 320, 320), ("lin_qkv_l0", 65536, 960, 320), ("lin_ff1_l0", 65536, 2560, 320), ("lin_ff2_l0", 65536, 320, 1280),
                         ("lin_ff1_l1", 16384, 5120, 640), ("lin_ff1_l2", 4096, 10240, 1280), ("lin_o_l2", 4096, 1280, 1280),
                         ("lin_l3", 1024, 1280, 1280)]:
     x = r(M, K)
     w = r(N, K, s=0.02)
     for tile in (128, 64):
-        ms = timeit(lambda: ops.gemm(x, w, tile=tile))
-        out.append(dict(k=name, tile=tile, ms=ms, tflops=2.0 * M * N * K / ms / 1e9))
+        for v in ("v1", "v2", "v3"):
+            ms = timeit(lambda: ops.gemm(x, w, tile=tile, v1=v == "v1", deep=v == "v3"))
+            out.append(dict(k=name, tile=tile, v=v, ms=ms, tflops=2.0 * M * N * K / ms / 1e9))
+    for cfg in (1, 2, 3, 4, 5):
+        ms = timeit(lambda: ops.gemm(x, w, cfg=cfg))
+        out.append(dict(k=name, tile=0, v="g3c%d" % cfg, ms=ms, tflops=2.0 * M * N * K / ms / 1e9))
+    if N % 16 == 0:
+        ms = timeit(lambda: ops.gemm(x, w, tile=128, geglu=True))
+        out.append(dict(k=name + "+geglu", tile=128, v="v2", ms=ms, tflops=2.0 * M * N * K / ms / 1e9))
 for (name, N, d) in [("attn_l0", 4096, 40), ("attn_l1", 1024, 80), ("attn_l2", 256, 160)]:
     C = 8 * d
     qkv = r(F * N, 3 * C, s=0.5)
