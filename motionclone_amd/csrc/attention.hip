@@ -16,6 +16,7 @@
 // softmax statistics are per-lane scalars and P^T feeds the next MFMA as its B
 // operand straight from the accumulator registers.
 #include "mc_common.hpp"
+#include <cstdlib>
 
 namespace mc {
 
@@ -80,20 +81,68 @@ __device__ __forceinline__ float grp_sum(float v) {
 }
 
 // ---- forward ----------------------------------------------------------------------------------
-template <int DT, int QT>
+// K/V tiles are double-buffered in LDS; the next tile's global loads are issued into registers before the current
+// tile's MFMAs and written to LDS after them (one barrier per tile).  Pairs of K=16 steps run as one
+// v_mfma_f32_16x16x32_f16 (cat4: concatenated fragments), the odd step of d = 40 / 80 as the K=16 instruction.
+template <int DT, int QT, bool PF>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int ldo, float* lse) {
     constexpr int RP = DT * 16 + 8;
+    constexpr int KS_HALFS = KV_TILE * RP;
+    constexpr int VT_HALFS = DT * 16 * TPAD;
+    constexpr int NV = (KV_TILE * DT * 2 + 255) / 256;  // 16-byte vectors per thread per staged matrix
     MC_DYN_SMEM(smem);
-    half_t* Ks = reinterpret_cast<half_t*>(smem);  // [64][RP]
-    half_t* Vt = Ks + KV_TILE * RP;                // [DT*16][TPAD]
+    constexpr int NB = PF ? 2 : 1;                      // LDS buffers per matrix
+    half_t* Ks0 = reinterpret_cast<half_t*>(smem);      // [NB][64][RP]
+    half_t* Vt0 = Ks0 + NB * KS_HALFS;                  // [NB][DT*16][TPAD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c15 = lane & 15;
     const int h = blockIdx.y, b = blockIdx.z;
     const int col0 = h * P.d;
     const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)(b / P.kv_bdiv) * P.Nk;
     const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int vpr = P.d / 8;
+    const float sl2 = P.scale * 1.4426950408889634f;  // scores are carried in log2 units
 
-    zero_pads<DT>(Ks, Vt, P.d);
+    zero_pads<DT>(Ks0, Vt0, P.d);
+    if (PF) zero_pads<DT>(Ks0 + KS_HALFS, Vt0 + VT_HALFS, P.d);
+
+    // per-thread staging slots: fixed (row, 16-byte column) of the 64-row tile; only the base row advances
+    half8_t rk[NV], rv[NV];
+    bool s_ok[NV];
+    int s_row[NV], s_lk[NV], s_lv[NV];
+    const half_t* s_pk[NV];
+    const half_t* s_pv[NV];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int idx = threadIdx.x + 256 * i;
+        int r = idx / vpr, vcol = idx - r * vpr;
+        s_ok[i] = idx < KV_TILE * vpr;
+        s_row[i] = r;
+        s_lk[i] = r * RP + vcol * 8;
+        s_lv[i] = vcol * 8 * TPAD + r;
+        s_pk[i] = P.k + (kbase + r) * P.ldk + col0 + vcol * 8;
+        s_pv[i] = P.v + (kbase + r) * P.ldv + col0 + vcol * 8;
+    }
+    auto load_regs = [&](int kv0) {
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            bool ok = s_ok[i] && kv0 + s_row[i] < P.Nk;
+            rk[i] = ok ? ld8(s_pk[i] + (size_t)kv0 * P.ldk) : zero8();
+            rv[i] = ok ? ld8(s_pv[i] + (size_t)kv0 * P.ldv) : zero8();
+        }
+    };
+    auto store_regs = [&](int buf) {
+        half_t* Ks = Ks0 + buf * KS_HALFS;
+        half_t* Vt = Vt0 + buf * VT_HALFS;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            if (s_ok[i]) {
+                *reinterpret_cast<half8_t*>(Ks + s_lk[i]) = rk[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) Vt[s_lv[i] + e * TPAD] = rv[i][e];
+            }
+        }
+    };
 
     half4_t qf[QT][DT];
 #pragma unroll
@@ -115,11 +164,25 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
         for (int dt = 0; dt < DT; ++dt) oacc[t][dt] = fzero4();
     }
 
+    if (PF) {
+        load_regs(0);
+        __syncthreads();  // pad zeroing done
+        store_regs(0);
+        __syncthreads();
+    }
+    int buf = 0;
     for (int kv0 = 0; kv0 < P.Nk; kv0 += KV_TILE) {
-        __syncthreads();
-        stage_rows<DT>(Ks, P.k, kbase, kv0, P.Nk, P.ldk, col0, P.d);
-        stage_cols(Vt, P.v, kbase, kv0, P.Nk, P.ldv, col0, P.d);
-        __syncthreads();
+        const bool more = kv0 + KV_TILE < P.Nk;
+        if (PF) {
+            if (more) load_regs(kv0 + KV_TILE);   // in flight during this tile's MFMAs
+        } else {
+            __syncthreads();                      // previous tile's reads done (and pad zeroing, first time)
+            load_regs(kv0);
+            store_regs(0);
+            __syncthreads();
+        }
+        const half_t* Ks = Ks0 + buf * KS_HALFS;
+        const half_t* Vt = Vt0 + buf * VT_HALFS;
 
         f32x4 st[QT][4];
 #pragma unroll
@@ -127,54 +190,83 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
 #pragma unroll
             for (int j = 0; j < 4; ++j) st[t][j] = fzero4();
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < 4; ++j) {
+            const half_t* krow = Ks + (16 * j + c15) * RP + 4 * g;
 #pragma unroll
-            for (int ks = 0; ks < DT; ++ks) {
-                half4_t kf = ld4(Ks + (16 * j + c15) * RP + 16 * ks + 4 * g);
+            for (int ks = 0; ks + 1 < DT; ks += 2) {
+                half8_t kf = cat4(ld4(krow + 16 * ks), ld4(krow + 16 * ks + 16));
 #pragma unroll
-                for (int t = 0; t < QT; ++t) st[t][j] = mfma16(kf, qf[t][ks], st[t][j]);
+                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, cat4(qf[t][ks], qf[t][ks + 1]), st[t][j]);
             }
-        half4_t pf[QT][4];
+            if (DT & 1) {
+                // odd step: same K=32 instruction with the upper k-slots zero.  (A dependent legacy 16x16x16 MFMA
+                // issued right behind 16x16x32 ones on the same accumulator returned wrong sums on gfx950.)
+                half8_t kf = cat4(ld4(krow + 16 * (DT - 1)), zero4());
+#pragma unroll
+                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, cat4(qf[t][DT - 1], zero4()), st[t][j]);
+            }
+        }
+        // online softmax in the exp2 domain: s2 = score * (scale * log2 e); masking only on the ragged last tile;
+        // the output accumulators are rescaled only when some row's running maximum actually moved
+        half8_t pf[QT][2];
+        const bool tail = kv0 + KV_TILE > P.Nk;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
             float mx = -INFINITY;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    int kv = kv0 + 16 * j + 4 * g + i;
-                    float s = kv < P.Nk ? st[t][j][i] * P.scale : -INFINITY;
-                    st[t][j][i] = s;
-                    mx = fmaxf(mx, s);
-                }
+                for (int i = 0; i < 4; ++i) st[t][j][i] *= sl2;
+            if (tail) {  // wave-uniform branch: only the ragged last tile pays for masking
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (kv0 + 16 * j + 4 * g + i >= P.Nk) st[t][j][i] = -INFINITY;
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, st[t][j][i]);
             mx = grp_max(mx);
             const float mnew = fmaxf(m[t], mx);
-            const float alpha = expf(m[t] - mnew);
             float rs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    float e = expf(st[t][j][i] - mnew);
+                    float e = fast_exp2(st[t][j][i] - mnew);
                     rs += e;
-                    pf[t][j][i] = (half_t)e;
+                    pf[t][j >> 1][4 * (j & 1) + i] = (half_t)e;
                 }
             rs = grp_sum(rs);
-            l[t] = l[t] * alpha + rs;
-            m[t] = mnew;
+            if (wave_all(mnew == m[t])) {
+                l[t] += rs;
+            } else {
+                const float alpha = fast_exp2(m[t] - mnew);
+                l[t] = l[t] * alpha + rs;
+                m[t] = mnew;
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt)
+                for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) oacc[t][dt][i] *= alpha;
+                    for (int i = 0; i < 4; ++i) oacc[t][dt][i] *= alpha;
+            }
         }
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
+        for (int dt = 0; dt < DT; ++dt) {
+            const half_t* vrow = Vt + (16 * dt + c15) * TPAD + 4 * g;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                half4_t vf = ld4(Vt + (16 * dt + c15) * TPAD + 16 * j + 4 * g);
+            for (int jp = 0; jp < 2; ++jp) {
+                half8_t vf = cat4(ld4(vrow + 32 * jp), ld4(vrow + 32 * jp + 16));
 #pragma unroll
-                for (int t = 0; t < QT; ++t) oacc[t][dt] = mfma16(vf, pf[t][j], oacc[t][dt]);
+                for (int t = 0; t < QT; ++t) oacc[t][dt] = mfma16k32(vf, pf[t][jp], oacc[t][dt]);
             }
+        }
+        if (PF) {
+            if (more) store_regs(buf ^ 1);
+            __syncthreads();
+            buf ^= 1;
+        }
     }
 
 #pragma unroll
@@ -192,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
                 st4(o + (qbase + qi) * ldo + col0 + c, ov);
             }
         }
-        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = m[t] + logf(l[t]);
+        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = (m[t] + log2f(l[t])) * 0.6931471805599453f;
     }
 }
 
@@ -388,16 +480,31 @@ static int a_check(const AParams& P) {
     return 1;
 }
 
+template <int DT, int QT, bool PF>
+static void a_launch_fwd_cfg(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
+    constexpr int RP = DT * 16 + 8;
+    size_t smem = (size_t)(PF ? 2 : 1) * (KV_TILE * RP + DT * 16 * TPAD) * sizeof(half_t);
+    allow_big_smem(attn_fwd_kernel<DT, QT, PF>, smem);
+    dim3 grid((P.Nq + 64 * QT - 1) / (64 * QT), P.heads, P.nbatch);
+    MC_LAUNCH((attn_fwd_kernel<DT, QT, PF>), grid, dim3(256), smem, s, P, o, ldo, lse);
+}
+
+// (query tiles per wave, register prefetch of the next K/V tile), chosen by measurement on MI355X
+// (profiles/r01_attention_config_sweep.txt): two query tiles per wave win at every level (half the LDS traffic per
+// query); the register prefetch never pays - the loop is VALU-bound on the softmax and occupancy matters more.
+// MC_ATTN_QT / MC_ATTN_PF override the choice for experiments.
 template <int DT>
 static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
-    constexpr int RP = DT * 16 + 8;
-    size_t smem = (size_t)(KV_TILE * RP + DT * 16 * TPAD) * sizeof(half_t);
-    if (P.Nq >= 512) {
-        dim3 grid((P.Nq + 127) / 128, P.heads, P.nbatch);
-        MC_LAUNCH((attn_fwd_kernel<DT, 2>), grid, dim3(256), smem, s, P, o, ldo, lse);
+    static const int qt_env = getenv("MC_ATTN_QT") ? atoi(getenv("MC_ATTN_QT")) : 0;
+    static const int pf_env = getenv("MC_ATTN_PF") ? atoi(getenv("MC_ATTN_PF")) : -1;
+    bool two = qt_env ? qt_env == 2 : P.Nq >= 256;
+    bool pf = pf_env >= 0 ? pf_env != 0 : false;
+    if (two) {
+        if (pf) a_launch_fwd_cfg<DT, 2, true>(P, o, ldo, lse, s);
+        else a_launch_fwd_cfg<DT, 2, false>(P, o, ldo, lse, s);
     } else {
-        dim3 grid((P.Nq + 63) / 64, P.heads, P.nbatch);
-        MC_LAUNCH((attn_fwd_kernel<DT, 1>), grid, dim3(256), smem, s, P, o, ldo, lse);
+        if (pf) a_launch_fwd_cfg<DT, 1, true>(P, o, ldo, lse, s);
+        else a_launch_fwd_cfg<DT, 1, false>(P, o, ldo, lse, s);
     }
 }
 template <int DT>

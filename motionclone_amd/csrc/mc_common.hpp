@@ -48,6 +48,7 @@ __device__ inline float shfl(float v, int src) { return hipemu::shfl(v, src); }
 __device__ inline int shfl(int v, int src) { return hipemu::shfl(v, src); }
 __device__ inline f32x4 mfma16(half4_t a, half4_t b, f32x4 c) { return hipemu::mfma_16x16x16(a, b, c); }
 __device__ inline f32x16 mfma32(half8_t a, half8_t b, f32x16 c) { return hipemu::mfma_32x32x16(a, b, c); }
+__device__ inline f32x4 mfma16k32(half8_t a, half8_t b, f32x4 c) { return hipemu::mfma_16x16x32(a, b, c); }
 __device__ inline float fast_exp(float x) { return expf(x); }
 __device__ inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #define MC_DYN_SMEM(name) char* name = hipemu::dyn_smem()
@@ -71,6 +72,10 @@ __device__ __forceinline__ f32x4 mfma16(half4_t a, half4_t b, f32x4 c) {
 // c[r] = C[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 __device__ __forceinline__ f32x16 mfma32(half8_t a, half8_t b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// D[16x16] += A[16x32] * B[32x16]; lane l: a = A[l&15][8*(l>>4)+j], b = B[8*(l>>4)+j][l&15], c as mfma16.
+__device__ __forceinline__ f32x4 mfma16k32(half8_t a, half8_t b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }
@@ -142,6 +147,19 @@ __device__ __forceinline__ void raw_barrier() {
 // 32-bit wrap in the range check.
 constexpr uint32_t kOOB = 0x80000000u;
 
+// true iff the predicate holds on all 64 lanes (wave-uniform result)
+#ifdef MC_EMU
+__device__ inline bool wave_all(bool p) {
+    int v = p ? 1 : 0;
+    for (int m = 32; m >= 1; m >>= 1) v &= hipemu::shfl_xor(v, m);
+    return v != 0;
+}
+__device__ inline float fast_exp2(float x) { return exp2f(x); }
+#else
+__device__ __forceinline__ bool wave_all(bool p) { return __all(p); }
+__device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
+#endif
+
 // reductions across the 64 lanes of a wave
 __device__ inline float wave_sum(float v) {
 #pragma unroll
@@ -174,6 +192,19 @@ __device__ inline void st4(half_t* p, half4_t v) { *reinterpret_cast<half4_t*>(p
 __device__ inline half8_t zero8() { half8_t z; for (int i = 0; i < 8; ++i) z[i] = (half_t)0.0f; return z; }
 __device__ inline half4_t zero4() { half4_t z; for (int i = 0; i < 4; ++i) z[i] = (half_t)0.0f; return z; }
 __device__ inline f32x4 fzero4() { f32x4 z = {0.f, 0.f, 0.f, 0.f}; return z; }
+
+// Two K=16 MFMA steps as one K=32 instruction: the contraction index may be permuted freely as long as both
+// operands use the same permutation, so the two half4 fragments of each operand are simply concatenated
+// (k-slots 0-3 of every lane group = first step, 4-7 = second step).
+__device__ inline half8_t cat4(half4_t lo, half4_t hi) {
+    half8_t r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        r[i] = lo[i];
+        r[4 + i] = hi[i];
+    }
+    return r;
+}
 
 // saturating float -> half (fp16 max 65504); keeps NaN out of downstream tensors on overflow
 __device__ inline half_t to_half(float x) {

@@ -93,26 +93,38 @@ __global__ void gn_finalize_kernel(const float* partial, float* stats, int frame
     }
 }
 
-// y = (x - mean) * rstd * gamma + beta, optional SiLU; out is [tokens][ctot] (ld = ldo)
+// y = (x - mean) * rstd * gamma + beta, optional SiLU; out is [tokens][ctot] (ld = ldo).
+// grid (nchunk, frames), block = VC * R threads: a thread owns one 8-channel vector column for the whole chunk, so
+// the per-channel scale / shift (rstd*gamma, beta - mean*rstd*gamma) are computed once and live in registers.
 __global__ void gn_apply_kernel(GnSrc s, const float* stats, const float* gamma, const float* beta,
-                                half_t* out, int ldo, long total_vec, int silu) {
+                                half_t* out, int ldo, int R, int nchunk, int silu) {
     const int VC = s.ctot / 8;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec;
-         idx += (long)gridDim.x * blockDim.x) {
-        long tok = idx / VC;
-        int c0 = (int)(idx - tok * VC) * 8;
-        int frame = (int)(tok / s.hw);
-        half8_t v = gn_load(s, (size_t)tok, c0);
+    const int t = threadIdx.x;
+    const int col = t % VC, r = t / VC;
+    if (r >= R) return;
+    const int frame = blockIdx.y, chunk = blockIdx.x;
+    const int per = (s.hw + nchunk - 1) / nchunk;
+    const int t0 = chunk * per;
+    const int t1 = min(s.hw, t0 + per);
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int c = col * 8 + e;
+        const float* st = stats + ((size_t)frame * 32 + c / s.cpg) * 2;
+        sc[e] = st[1] * gamma[c];
+        sh[e] = beta[c] - st[0] * sc[e];
+    }
+    for (int tk = t0 + r; tk < t1; tk += R) {
+        size_t tok = (size_t)frame * s.hw + tk;
+        half8_t v = gn_load(s, tok, col * 8);
         half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int c = c0 + e;
-            const float* st = stats + ((size_t)frame * 32 + c / s.cpg) * 2;
-            float y = ((float)v[e] - st[0]) * st[1] * gamma[c] + beta[c];
+            float y = (float)v[e] * sc[e] + sh[e];
             if (silu) y = silu_f(y);
             o[e] = to_half(y);
         }
-        st8(out + (size_t)tok * ldo + c0, o);
+        st8(out + tok * ldo + col * 8, o);
     }
 }
 
@@ -178,96 +190,148 @@ __global__ void gn_bwd_partial_kernel(GnSrc s, const half_t* dz, int lddz, const
     }
 }
 
-// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); optional accumulate into dx
+// dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); optional accumulate into dx.  Same thread layout
+// as gn_apply_kernel (per-channel constants in registers).
 __global__ void gn_bwd_apply_kernel(GnSrc s, const half_t* dz, int lddz, const float* stats,
                                     const float* bstats, const float* gamma, const float* beta, int silu,
-                                    half_t* dx, int lddx, long total_vec, int accumulate) {
+                                    half_t* dx, int lddx, int R, int nchunk, int accumulate) {
     const int VC = s.ctot / 8;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_vec;
-         idx += (long)gridDim.x * blockDim.x) {
-        long tok = idx / VC;
-        int c0 = (int)(idx - tok * VC) * 8;
-        int frame = (int)(tok / s.hw);
-        half8_t x = gn_load(s, (size_t)tok, c0);
-        half8_t g = ld8(dz + (size_t)tok * lddz + c0);
-        half8_t o;
+    const int t = threadIdx.x;
+    const int col = t % VC, r = t / VC;
+    if (r >= R) return;
+    const int frame = blockIdx.y, chunk = blockIdx.x;
+    const int per = (s.hw + nchunk - 1) / nchunk;
+    const int t0 = chunk * per;
+    const int t1 = min(s.hw, t0 + per);
+    float mean[8], rstd[8], gm[8], bt[8], m1[8], m2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        int c = col * 8 + e;
+        size_t gi = ((size_t)frame * 32 + c / s.cpg) * 2;
+        mean[e] = stats[gi];
+        rstd[e] = stats[gi + 1];
+        m1[e] = bstats[gi];
+        m2[e] = bstats[gi + 1];
+        gm[e] = gamma[c];
+        bt[e] = beta[c];
+    }
+    for (int tk = t0 + r; tk < t1; tk += R) {
+        size_t tok = (size_t)frame * s.hw + tk;
+        half8_t x = gn_load(s, tok, col * 8);
+        half8_t g = ld8(dz + tok * lddz + col * 8);
         half8_t prev;
-        if (accumulate) prev = ld8(dx + (size_t)tok * lddx + c0);
+        if (accumulate) prev = ld8(dx + tok * lddx + col * 8);
+        half8_t o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            int c = c0 + e;
-            size_t gi = ((size_t)frame * 32 + c / s.cpg) * 2;
-            float mean = stats[gi], rstd = stats[gi + 1];
-            float m1 = bstats[gi], m2 = bstats[gi + 1];
-            float xh = ((float)x[e] - mean) * rstd;
+            float xh = ((float)x[e] - mean[e]) * rstd[e];
             float dy = (float)g[e];
-            if (silu) dy *= silu_grad_f(xh * gamma[c] + beta[c]);
-            float v = rstd * (dy * gamma[c] - m1 - xh * m2);
+            if (silu) dy *= silu_grad_f(xh * gm[e] + bt[e]);
+            float v = rstd[e] * (dy * gm[e] - m1[e] - xh * m2[e]);
             if (accumulate) v += (float)prev[e];
             o[e] = to_half(v);
         }
-        st8(dx + (size_t)tok * lddx + c0, o);
+        st8(dx + tok * lddx + col * 8, o);
     }
 }
 
 // ---- LayerNorm: one wave per row, row kept in registers ----------------------------------
+// A wave walks LN_RPW consecutive rows (fully unrolled, so the loads of all of them are in flight together).
+// gamma / beta of the lane's 8-channel vectors are loaded once per wave as 16-byte vectors.
+constexpr int LN_RPW = 4;
+
+__device__ __forceinline__ void ld8f(const float* p, float (&d)[8]) {
+    f32x4 a = *reinterpret_cast<const f32x4*>(p);
+    f32x4 b = *reinterpret_cast<const f32x4*>(p + 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        d[e] = a[e];
+        d[4 + e] = b[e];
+    }
+}
+
 template <int NV>
 __global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* x, int ldx, half_t* y, int ldy,
                                                       const float* gamma, const float* beta,
                                                       const float* pe, int hw, int nframes_pe,
                                                       float* stats, int M, int C, float eps) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const bool live = row < M;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_RPW;
     const int nvec = C / 8;
-    half8_t v[NV];
-    float sum = 0.f;
+    float gam[NV][8], bet[NV][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int vi = lane + 64 * i;
-        if (live && vi < nvec) {
-            v[i] = ld8(x + (size_t)row * ldx + vi * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+        if (vi < nvec) {
+            ld8f(gamma + vi * 8, gam[i]);
+            ld8f(beta + vi * 8, bet[i]);
         } else {
-            v[i] = zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gam[i][e] = bet[i][e] = 0.f;
         }
     }
-    sum = wave_sum(sum);
-    const float mean = sum / C;
-    float sq = 0.f;
+    half8_t v[LN_RPW][NV];
+    float mean[LN_RPW], rstd[LN_RPW];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        int vi = lane + 64 * i;
-        if (vi < nvec) {
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        const int row = row0 + rr;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float d = (float)v[i][e] - mean;
-                sq += d * d;
-            }
+        for (int i = 0; i < NV; ++i) {
+            int vi = lane + 64 * i;
+            v[rr][i] = (row < M && vi < nvec) ? ld8(x + (size_t)row * ldx + vi * 8) : zero8();
         }
     }
-    sq = wave_sum(sq);
-    const float rstd = 1.0f / sqrtf(sq / C + eps);
-    if (!live) return;
-    if (lane == 0 && stats) {
-        stats[(size_t)row * 2] = mean;
-        stats[(size_t)row * 2 + 1] = rstd;
+#pragma unroll
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += (float)v[rr][i][e];
+        mean[rr] = wave_sum(sum) / C;
     }
-    const float* perow = pe ? pe + (size_t)((row / hw) % nframes_pe) * C : nullptr;
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        int vi = lane + 64 * i;
-        if (vi < nvec) {
-            half8_t o;
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        float sq = 0.f;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                int c = vi * 8 + e;
-                float t = ((float)v[i][e] - mean) * rstd * gamma[c] + beta[c];
-                if (perow) t += perow[c];
-                o[e] = to_half(t);
+        for (int i = 0; i < NV; ++i) {
+            int vi = lane + 64 * i;
+            if (vi < nvec) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float d = (float)v[rr][i][e] - mean[rr];
+                    sq += d * d;
+                }
             }
-            st8(y + (size_t)row * ldy + vi * 8, o);
+        }
+        rstd[rr] = 1.0f / sqrtf(wave_sum(sq) / C + eps);
+    }
+#pragma unroll
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        const int row = row0 + rr;
+        if (row >= M) continue;
+        if (lane == 0 && stats) {
+            stats[(size_t)row * 2] = mean[rr];
+            stats[(size_t)row * 2 + 1] = rstd[rr];
+        }
+        const float* perow = pe ? pe + (size_t)((row / hw) % nframes_pe) * C : nullptr;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int vi = lane + 64 * i;
+            if (vi < nvec) {
+                float pv[8];
+                if (perow) {
+                    ld8f(perow + vi * 8, pv);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+                }
+                half8_t o;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    o[e] = to_half(((float)v[rr][i][e] - mean[rr]) * rstd[rr] * gam[i][e] + bet[i][e] + pv[e]);
+                st8(y + (size_t)row * ldy + vi * 8, o);
+            }
         }
     }
 }
@@ -279,48 +343,63 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const half_t* dy, int lddy,
                                                       const half_t* add, int ldadd, half_t* dx, int lddx,
                                                       int M, int C) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    const bool live = row < M;
+    const int row0 = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * LN_RPW;
     const int nvec = C / 8;
-    const float mean = live ? stats[(size_t)row * 2] : 0.f;
-    const float rstd = live ? stats[(size_t)row * 2 + 1] : 0.f;
-    float g[NV][8], xh[NV][8];
-    float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        int vi = lane + 64 * i;
-        if (live && vi < nvec) {
-            half8_t xv = ld8(x + (size_t)row * ldx + vi * 8);
-            half8_t dv = ld8(dy + (size_t)row * lddy + vi * 8);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                xh[i][e] = ((float)xv[e] - mean) * rstd;
-                g[i][e] = (float)dv[e] * gamma[vi * 8 + e];
-                s1 += g[i][e];
-                s2 += g[i][e] * xh[i][e];
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) xh[i][e] = g[i][e] = 0.f;
-        }
-    }
-    s1 = wave_sum(s1) / C;
-    s2 = wave_sum(s2) / C;
-    if (!live) return;
+    float gam[NV][8];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int vi = lane + 64 * i;
         if (vi < nvec) {
-            half8_t o;
-            half8_t av;
-            if (add) av = ld8(add + (size_t)row * ldadd + vi * 8);
+            ld8f(gamma + vi * 8, gam[i]);
+        } else {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float t = rstd * (g[i][e] - s1 - xh[i][e] * s2);
-                if (add) t += (float)av[e];
-                o[e] = to_half(t);
+            for (int e = 0; e < 8; ++e) gam[i][e] = 0.f;
+        }
+    }
+#pragma unroll 2
+    for (int rr = 0; rr < LN_RPW; ++rr) {
+        const int row = row0 + rr;
+        const bool live = row < M;
+        const float mean = live ? stats[(size_t)row * 2] : 0.f;
+        const float rstd = live ? stats[(size_t)row * 2 + 1] : 0.f;
+        float g[NV][8], xh[NV][8];
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int vi = lane + 64 * i;
+            if (live && vi < nvec) {
+                half8_t xv = ld8(x + (size_t)row * ldx + vi * 8);
+                half8_t dv = ld8(dy + (size_t)row * lddy + vi * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    xh[i][e] = ((float)xv[e] - mean) * rstd;
+                    g[i][e] = (float)dv[e] * gam[i][e];
+                    s1 += g[i][e];
+                    s2 += g[i][e] * xh[i][e];
+                }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xh[i][e] = g[i][e] = 0.f;
             }
-            st8(dx + (size_t)row * lddx + vi * 8, o);
+        }
+        s1 = wave_sum(s1) / C;
+        s2 = wave_sum(s2) / C;
+        if (!live) continue;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            int vi = lane + 64 * i;
+            if (vi < nvec) {
+                half8_t o;
+                half8_t av;
+                if (add) av = ld8(add + (size_t)row * ldadd + vi * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float t = rstd * (g[i][e] - s1 - xh[i][e] * s2);
+                    if (add) t += (float)av[e];
+                    o[e] = to_half(t);
+                }
+                st8(dx + (size_t)row * lddx + vi * 8, o);
+            }
         }
     }
 }
@@ -379,10 +458,11 @@ extern "C" int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int
                                       const float* beta, void* out, int ldo, int silu, void* stream) {
     GnSrc s;
     if (!make_src(&s, a, b, lda, ldb, c1, ctot, hw) || ldo % 8) return MC_ERR_SHAPE;
-    long total = (long)frames * hw * (ctot / 8);
-    int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-    MC_LAUNCH(gn_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, stats, gamma, beta,
-              (half_t*)out, ldo, total, silu);
+    int R, threads;
+    if (!gn_geometry(ctot, &R, &threads)) return MC_ERR_UNSUPPORTED;
+    int nchunk = mc_gn_nchunk(hw);
+    MC_LAUNCH(gn_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, stats, gamma, beta,
+              (half_t*)out, ldo, R, nchunk, silu);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
@@ -402,10 +482,8 @@ extern "C" int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int l
     int n = frames * 32;
     MC_LAUNCH(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
               (const float*)partial, bstats, frames, nchunk, (float)hw * s.cpg, 0.f, 1);
-    long total = (long)frames * hw * (ctot / 8);
-    int blocks = (int)std::min<long>((total + 255) / 256, 4096);
-    MC_LAUNCH(gn_bwd_apply_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, s, (const half_t*)dz,
-              lddz, stats, (const float*)bstats, gamma, beta, silu, (half_t*)dx, lddx, total, accumulate);
+    MC_LAUNCH(gn_bwd_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, (const half_t*)dz,
+              lddz, stats, (const float*)bstats, gamma, beta, silu, (half_t*)dx, lddx, R, nchunk, accumulate);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
@@ -414,7 +492,7 @@ extern "C" int mc_layernorm_fwd_f16(const void* x, int ldx, void* y, int ldy, co
                                     float* stats, int M, int C, float eps, void* stream) {
     if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || C > 1536) return MC_ERR_SHAPE;
     if (pe && (hw <= 0 || nframes_pe <= 0)) return MC_ERR_SHAPE;
-    dim3 grid((M + 3) / 4), block(256);
+    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
     hipStream_t s = (hipStream_t)stream;
     int nv = (C / 8 + 63) / 64;
     if (nv == 1)
@@ -434,7 +512,7 @@ extern "C" int mc_layernorm_bwd_f16(const void* dy, int lddy, const void* x, int
                                     int M, int C, void* stream) {
     if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || lddy % 8 || lddx % 8 || C > 1536) return MC_ERR_SHAPE;
     if (add && ldadd % 8) return MC_ERR_SHAPE;
-    dim3 grid((M + 3) / 4), block(256);
+    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
     hipStream_t s = (hipStream_t)stream;
     int nv = (C / 8 + 63) / 64;
     if (nv == 1)

@@ -155,6 +155,26 @@ inline f4 mfma_16x16x16(h4 a, h4 b, f4 c) {
     return c;
 }
 
+// v_mfma_f32_16x16x32_f16: lane l holds A[l&15][8*(l>>4)+j], B[8*(l>>4)+j][l&15]; D[4*(l>>4)+i][l&15].
+inline f4 mfma_16x16x32(h8 a, h8 b, f4 c) {
+    struct { h8 a, b; } mine{a, b};
+    auto buf = exchange(&mine, sizeof(mine));
+    int l = lane_id();
+    int col = l & 15, g = l >> 4;
+    for (int i = 0; i < 4; ++i) {
+        int row = 4 * g + i;
+        float acc = c[i];
+        for (int k = 0; k < 32; ++k) {
+            decltype(mine) A, B;
+            std::memcpy(&A, buf[row + 16 * (k >> 3)], sizeof(A));
+            std::memcpy(&B, buf[col + 16 * (k >> 3)], sizeof(B));
+            acc += (float)A.a[k & 7] * (float)B.b[k & 7];
+        }
+        c[i] = acc;
+    }
+    return c;
+}
+
 // v_mfma_f32_32x32x16_f16: lane l holds A[l&31][8*(l>>5)+j], B[8*(l>>5)+j][l&31];
 // D[(r&3) + 8*(r>>2) + 4*(l>>5)][l&31].
 inline f16v mfma_32x32x16(h8 a, h8 b, f16v c) {
