@@ -33,9 +33,23 @@ TFLOP_GUIDED, TFLOP_PLAIN, TFLOP_EXTRACT = 45.50, 35.35, 10.06
 PEAK_FP16_MFMA_TFLOPS = 2500.0
 
 
+def gemm_kernel_name(mode, M, N):
+    """Which kernel instance mc_gemm_f16 picks in auto mode (mirrors the heuristic in csrc/gemm.hip)."""
+    modes = {ops.DENSE: "DENSE", ops.CONV_S1: "CONV_S1", ops.CONV_S2: "CONV_S2", ops.CONV_UP: "CONV_UP",
+             ops.TCONV_S2: "TCONV_S2"}
+    if N % 320 == 0:
+        if ((M + 255) // 256) * (N // 320) >= 224:
+            return "gemm3_kernel<%s,256,320,4,2>" % modes[mode]
+        if ((M + 127) // 128) * (N // 320) >= 192:
+            return "gemm3_kernel<%s,128,320,2,2>" % modes[mode]
+    if ((M + 127) // 128) * ((N + 127) // 128) < 256:
+        return "gemm2_kernel<%s,64,64,2>" % modes[mode]
+    return "gemm2_kernel<%s,128,128,2>" % modes[mode]
+
+
 class GemmProbe:
-    """HIP-event timing of every launch of the dominant kernel (implicit-GEMM 3x3 conv, 128x128 tile) inside the
-    timed region.  The kernel is launched on torch's current stream, which is where the events are recorded."""
+    """HIP-event timing of every GEMM / implicit-conv launch inside the timed region, grouped by kernel instance.
+    The kernels are launched on torch's current stream, which is where the events are recorded."""
 
     def __init__(self):
         self.events = []
@@ -46,28 +60,36 @@ class GemmProbe:
         probe = self
 
         def gemm(a, w, **kw):
+            if not probe.enabled:
+                return probe._orig(a, w, **kw)
             mode = kw.get("mode", ops.DENSE)
-            if not probe.enabled or mode != ops.CONV_S1:
-                return probe._orig(a, w, **kw)
             N, K = w.shape
-            M = kw["m_out"]
-            if ((M + 127) // 128) * ((N + 127) // 128) < 256:   # the C side picks the 64x64 tile
-                return probe._orig(a, w, **kw)
+            M = kw["m_out"] if mode != ops.DENSE else a.shape[0]
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             out = probe._orig(a, w, **kw)
             e1.record()
-            probe.events.append((e0, e1, 2.0 * M * N * K))
+            n_out = N // 2 if kw.get("geglu") else N
+            # algorithmic bytes: every operand once (activations, weights, residual, output)
+            nbytes = 2.0 * (a.shape[0] * a.shape[1] + (kw["a2"].numel() if kw.get("a2") is not None else 0)
+                            + N * K + M * n_out * (2 if kw.get("residual") is not None else 1))
+            probe.events.append((gemm_kernel_name(mode, M, N), e0, e1, 2.0 * M * N * K, nbytes))
             return out
         ops.gemm = gemm
 
     def summary(self):
-        if not self.events:
-            return None
-        ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.events)
-        fl = sum(f for _, _, f in self.events)
-        return dict(launches=len(self.events), avg_us=1e3 * ms / len(self.events), total_ms=ms,
-                    tflops=fl / ms / 1e9, flop_per_launch=fl / len(self.events))
+        groups = {}
+        for name, e0, e1, fl, nb in self.events:
+            g = groups.setdefault(name, dict(launches=0, ms=0.0, flop=0.0, bytes=0.0))
+            g["launches"] += 1
+            g["ms"] += e0.elapsed_time(e1)
+            g["flop"] += fl
+            g["bytes"] += nb
+        for g in groups.values():
+            g["avg_us"] = 1e3 * g["ms"] / g["launches"]
+            g["tflops"] = g["flop"] / g["ms"] / 1e9
+            g["alg_gbps"] = g["bytes"] / g["ms"] / 1e6
+        return groups
 
 
 def synth_inputs(dev, F, H, W, seed):
@@ -205,18 +227,22 @@ def main():
         psec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if not g]
         videos = args.steps * world
         tflop_video = G_STEPS * TFLOP_GUIDED + (N_STEPS - G_STEPS) * TFLOP_PLAIN + TFLOP_EXTRACT
-        ps = probe.summary()
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic_conv_gemm.json")
+        groups = probe.summary()
+        traffic_tab = {}
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")
         if os.path.exists(tfile):
-            traffic = json.load(open(tfile)).get("bytes_per_launch")
-        roof = None
-        if ps:
-            roof = dict(bound="mfma", kernel="gemm_kernel<CONV_S1,128,128> (implicit-GEMM 3x3 conv)",
-                        achieved=ps["tflops"], peak=PEAK_FP16_MFMA_TFLOPS, unit="TFLOP/s",
-                        frac=ps["tflops"] / PEAK_FP16_MFMA_TFLOPS, traffic=traffic, launches=ps["launches"],
-                        avg_launch_us=ps["avg_us"], flop_per_launch=ps["flop_per_launch"],
-                        share_of_timed_region=ps["total_ms"] / 1e3 / (elapsed / 1.0) if world == 1 else None)
+            traffic_tab = json.load(open(tfile))
+        roof, roof_all = None, {}
+        if groups:
+            for name, g in groups.items():
+                roof_all[name] = dict(bound="mfma", achieved=g["tflops"], peak=PEAK_FP16_MFMA_TFLOPS, unit="TFLOP/s",
+                                      frac=g["tflops"] / PEAK_FP16_MFMA_TFLOPS, launches=g["launches"],
+                                      avg_launch_us=g["avg_us"], flop_per_launch=g["flop"] / g["launches"],
+                                      algorithmic_bytes_per_launch=g["bytes"] / g["launches"],
+                                      algorithmic_gbps=g["alg_gbps"], traffic=traffic_tab.get(name),
+                                      share_of_timed_region=(g["ms"] / 1e3 / elapsed) if world == 1 else None)
+            dom = max(groups, key=lambda n: groups[n]["ms"])   # dominant by time inside the timed region
+            roof = dict(roof_all[dom], kernel=dom)
         res = {
             "metric": "videos/min (16f x 512x512 SD1.5+AnimateDiff-v3 arch, 30-step DDIM, 18 guided, MotionClone guidance)",
             "value": videos / (elapsed / 60.0), "unit": "videos/min", "n_gpus": world, "steps": args.steps,
@@ -231,6 +257,7 @@ def main():
             "e2e_tflops_per_gpu": tflop_video * args.steps / elapsed,
             "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
             "roofline": roof,
+            "roofline_by_kernel": roof_all,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()

@@ -38,7 +38,8 @@ int mc_version(void);
  * mode 3 CONV_UP  : F.interpolate(nearest, 2x) + 3x3 (resnet.py:65,78), upsample never materialised
  * mode 4 TCONV_S2 : data-gradient of mode 2
  * A2 (optional) supplies channels [c1, ctot) - the skip concat of unet_blocks.py:634,740.
- * K = ctot (dense) or 9*ctot (conv; k = tap*ctot + c).  K, ctot, c1 multiples of 64; N, ldc multiples of 4.
+ * K = ctot (dense) or 9*ctot (conv; k = (c/64)*576 + tap*64 + c%64: channel-tile major, tap minor).
+ * K, ctot, c1 multiples of 64; N, ldc multiples of 4.
  * flags: bits 0-7 block tile edge (0 = auto, 64, 128); 0x100 = force the first-generation kernel;
  *        0x200 = fused GEGLU epilogue: W rows interleaved (h_j, gate_j), C gets N/2 columns h_j * gelu(gate_j). */
 int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,

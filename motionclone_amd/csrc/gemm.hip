@@ -78,9 +78,10 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
     auto load_tiles = [&](int kt) {
         const int k0 = kt * BK;
         int tap = 0, c0 = k0;
-        if (MODE != DENSE) {
-            tap = k0 / p.ctot;
-            c0 = k0 - tap * p.ctot;
+        if (MODE != DENSE) {  // K order: 64-channel tile major, tap minor (the 9 taps of a channel tile are adjacent)
+            const int ct = kt / 9;
+            tap = kt - 9 * ct;
+            c0 = ct * BK;
         }
         const half_t* src = p.A;
         int ld = p.lda;

@@ -75,9 +75,10 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p, uint32_t bytes
     auto issue_tiles = [&](int kt, int buf) {
         const int k0 = kt * BK;
         int tap = 0, c0 = k0;
-        if (MODE != DENSE) {
-            tap = k0 / p.ctot;
-            c0 = k0 - tap * p.ctot;
+        if (MODE != DENSE) {  // K order: 64-channel tile major, tap minor (the 9 taps of a channel tile are adjacent)
+            const int ct = kt / 9;
+            tap = kt - 9 * ct;
+            c0 = ct * BK;
         }
         const bool second = c0 >= p.c1;
         const int ld = second ? p.lda2 : p.lda;

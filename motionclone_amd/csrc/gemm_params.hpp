@@ -16,7 +16,9 @@ struct GemmParams {
     int M, N, K;
     int lda, lda2, ldc, ldr;
     int c1;     // channels taken from A; the rest (ctot - c1) come from A2
-    int ctot;   // channels per tap (conv) or K (dense)
+    int ctot;   // channels per tap (conv) or K (dense).  Conv K index: k = (c / 64) * 576 + tap * 64 + (c % 64), i.e.
+                // the 9 taps of one 64-channel tile are consecutive K tiles: a workgroup re-reads the same 32 KiB of
+                // activations 9 times back to back (L2 hits) instead of once per pass over all channels.
     int Hs, Ws; // source grid (per frame)
     int Ho, Wo; // output grid (per frame)
     int rows_per_batch;

@@ -104,7 +104,7 @@ class Weights:
             w = self.sd[name].to(torch.float32).permute(0, 2, 3, 1)  # [Cout, 3, 3, Cin]
             if pad_cin and w.shape[3] < pad_cin:
                 w = torch.nn.functional.pad(w, (0, pad_cin - w.shape[3]))
-            return self._h(w.reshape(w.shape[0], -1))
+            return self._h(ops.pack_conv_k(w.reshape(w.shape[0], 9, w.shape[3])))
         return self._get(("conv", name, pad_cin), mk)
 
     def conv_dgrad(self, name, stride=1, pad_cin=0):
@@ -114,7 +114,7 @@ class Weights:
             if stride == 1:
                 w = w.flip(2, 3)
             w = w.permute(1, 2, 3, 0)  # [Cin, 3, 3, Cout]
-            w = w.reshape(w.shape[0], -1)
+            w = ops.pack_conv_k(w.reshape(w.shape[0], 9, w.shape[3]))
             if pad_cin and w.shape[0] < pad_cin:
                 w = torch.nn.functional.pad(w, (0, 0, 0, pad_cin - w.shape[0]))
             return self._h(w)

@@ -78,6 +78,13 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
     return out
 
 
+def pack_conv_k(w_taps):
+    """[N, 9, C] (tap-major) -> [N, 9*C] in the kernels' K order: 64-channel tile major, tap minor."""
+    N, T, C = w_taps.shape
+    assert T == 9 and C % 64 == 0
+    return w_taps.reshape(N, 9, C // 64, 64).permute(0, 2, 1, 3).reshape(N, 9 * C).contiguous()
+
+
 def interleave_geglu(t):
     """rows [h_0..h_{D-1}, g_0..g_{D-1}] -> [h_0, g_0, h_1, g_1, ...] (weight [2D, K] or bias [2D])"""
     D = t.shape[0] // 2

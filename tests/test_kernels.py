@@ -111,8 +111,8 @@ def test_gemm_concat_and_strided_out(backend, v1):
     assert wide[:, :N].abs().max() == 0 and wide[:, 2 * N:].abs().max() == 0
 
 
-def _conv_w_pack(w):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin] tap-major
-    return w.permute(0, 2, 3, 1).reshape(w.shape[0], -1).contiguous()
+def _conv_w_pack(w):  # [Cout, Cin, 3, 3] -> [Cout, 9*Cin] in the kernels' K order
+    return ops.pack_conv_k(w.permute(0, 2, 3, 1).reshape(w.shape[0], 9, w.shape[1]))
 
 
 def _to_cl(x):  # [NF, C, H, W] -> [NF*H*W, C]
@@ -166,10 +166,10 @@ def test_conv3x3_dgrad(backend, stride, v1):
     (ref,) = torch.autograd.grad(y, x, dy.float())
     Ho, Wo = y.shape[2:]
     if stride == 1:
-        wd = w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+        wd = ops.pack_conv_k(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))
         out = ops.gemm(_to_cl(dy), wd, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, v1=v1)
     else:
-        wd = w.permute(1, 2, 3, 0).reshape(Cin, 9 * Cout).contiguous()
+        wd = ops.pack_conv_k(w.permute(1, 2, 3, 0).reshape(Cin, 9, Cout))
         out = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(Ho, Wo, H, W), m_out=NF * H * W, v1=v1)
     close(_from_cl(out, NF, H, W), ref, 3e-2, 5e-3, "conv dgrad s%d" % stride)
 
