@@ -105,15 +105,15 @@ def synth_inputs(dev, F, H, W, seed):
     return lat, text, vid, noise
 
 
-def one_video(smp, lat, text, vid, noise, step_events=None):
-    rep = smp.extract(vid, noise, text[0:1], add_noise_step=400)
+def one_video(smp, lat, text, vid, noise, step_events=None, ctrl=None):
+    rep = smp.extract(vid, noise, text[0:1], add_noise_step=400, ctrl=ctrl)
     rep_dev = smp.engine.prepare_representation(rep)
     x = lat
     for i in range(len(smp.timesteps)):
         if step_events is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        x = smp.step(x, i, text, rep_dev)
+        x = smp.step(x, i, text, rep_dev, ctrl=ctrl)
         if step_events is not None:
             e1.record()
             step_events.append((i < smp.G, e0, e1))
@@ -161,6 +161,10 @@ def main():
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ddim-steps", type=int, default=30)
+    ap.add_argument("--guided-steps", type=int, default=18)
+    ap.add_argument("--guidance-scale", type=float, default=0.4)
+    ap.add_argument("--sparsectrl", action="store_true", help="BASELINE config 4: add the SparseCtrl (i2v_rgb) encoder pass")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -190,17 +194,28 @@ def main():
             sd[name] = flat[off:off + n].view(shape)
             off += n
     eng = UNet3DEngine(sd, cfg, dev)
-    N_STEPS, G_STEPS, G_SCALE = 30, 18, 0.4
+    N_STEPS, G_STEPS, G_SCALE = args.ddim_steps, args.guided_steps, args.guidance_scale
+    ceng = None
+    if args.sparsectrl:
+        from motionclone_amd.engine import ControlNetEngine
+        ceng = ControlNetEngine(spec.synthetic_controlnet_state_dict(cfg, seed=4321, device=dev), cfg, dev)
     smp = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
-                             num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE)
+                             num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng)
     # per-rank example seeds as in configs/t2v_camera.jsonl (42, 42, 2026, default 2025, ...)
     seeds = [42, 42, 2026, 2025, 2026, 2026, 2026, 2025]
     lat, text, vid, noise = synth_inputs(dev, args.frames, args.size, args.size, seeds[rank % len(seeds)])
+    ctrl = None
+    if args.sparsectrl:   # one condition image (its VAE latent, synthetic) on frame 0, as configs/i2v_rgb.jsonl does
+        cond = torch.zeros_like(vid)
+        mask = torch.zeros_like(vid[:, :1])
+        cond[:, :, 0] = vid[:, :, 0]
+        mask[:, :, 0] = 1
+        ctrl = dict(cond=cond, mask=mask, scale=1.0)
 
     probe = GemmProbe()
     probe.install()
     for _ in range(args.warmup):
-        out = one_video(smp, lat, text, vid, noise)
+        out = one_video(smp, lat, text, vid, noise, ctrl=ctrl)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -209,7 +224,7 @@ def main():
     step_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = one_video(smp, lat, text, vid, noise, step_events)
+        out = one_video(smp, lat, text, vid, noise, step_events, ctrl=ctrl)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -226,7 +241,10 @@ def main():
         gsec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if g]
         psec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if not g]
         videos = args.steps * world
-        tflop_video = G_STEPS * TFLOP_GUIDED + (N_STEPS - G_STEPS) * TFLOP_PLAIN + TFLOP_EXTRACT
+        # algorithmic work of the reference graph per step; only tabulated for the BASELINE shapes
+        table = {(16, 256): (10.41, 8.17, 2.39), (16, 512): (45.50, 35.35, 10.06), (32, 768): (235.9, 181.1, 49.7)}
+        tg, tp, te = table.get((args.frames, args.size), (float("nan"),) * 3)
+        tflop_video = G_STEPS * tg + (N_STEPS - G_STEPS) * tp + te
         groups = probe.summary()
         traffic_tab = {}
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")
@@ -248,9 +266,13 @@ def main():
             "value": videos / (elapsed / 60.0), "unit": "videos/min", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE config 2: t2v_object-style sample, 16 frames, %dx%d, UNet only "
-                                   "(extraction + 18 guided + 12 plain DDIM steps), schedule (30,18,0.4)"
-                                   % (args.size, args.size),
+            "config": {"workload": "BASELINE config %s: %d frames, %dx%d, UNet%s only (extraction + %d guided + %d plain "
+                                   "DDIM steps), schedule (%d,%d,%g)"
+                                   % ("4 (i2v_rgb + SparseCtrl)" if args.sparsectrl else
+                                      {(16, 512): "2 (t2v_object-style)", (32, 768): "5 (long clip)",
+                                       (16, 256): "1 shape"}.get((args.frames, args.size), "custom"),
+                                      args.frames, args.size, args.size, " + SparseCtrl" if args.sparsectrl else "",
+                                      G_STEPS, N_STEPS - G_STEPS, N_STEPS, G_STEPS, G_SCALE),
                        "videos_per_gpu": args.steps, "parallelism": "replicas x%d" % world},
             "sec_per_guided_step": sum(gsec) / max(1, len(gsec)), "sec_per_plain_step": sum(psec) / max(1, len(psec)),
             "sec_per_denoise_step": (sum(gsec) + sum(psec)) / max(1, len(gsec) + len(psec)),

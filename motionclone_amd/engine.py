@@ -346,7 +346,8 @@ class UNet3DEngine:
         h = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
         del hn
         saved = []
-        for a in range(2):
+        n_attn = 2 if (b + "attention_blocks.1.to_q.weight") in w.sd else 1   # SparseCtrl modules have one
+        for a in range(n_attn):
             ap = b + "attention_blocks.%d." % a
             aname = ap[:-1]
             n, ls = ops.layernorm_fwd(h, w.vec(b + "norms.%d.weight" % a), w.vec(b + "norms.%d.bias" % a), pe=pe, hw=hw,
@@ -386,7 +387,7 @@ class UNet3DEngine:
                 dff1 = ops.geglu_bwd(dg, ff1)
                 dn = ops.gemm(dff1, w.lin_t(b + "ff.net.0.proj.weight"))
                 dh = ops.layernorm_bwd(dn, h2, lsf, w.vec(b + "ff_norm.weight"), add=dh3)
-            for a in (1, 0):
+            for a in reversed(range(n_attn)):
                 hin, ls, qkv, aname, ap = saved[a]
                 seed = seeds.get(aname) if seeds is not None else None
                 if dh is None and seed is None:
@@ -482,10 +483,23 @@ class UNet3DEngine:
                 x, geo = self._downsample("down_blocks.%d.downsamplers.0.conv." % i, x, geo, tape)
                 skips.append((x, geo))
         if down_residuals is not None:
-            raise NotImplementedError("SparseCtrl residuals: SURVEY.md 8a A16 is scheduled after the t2v path")
+            # SparseCtrl: res_samples[i] += residual[i] on the skip copies only (motionclone_functions.py:581-587);
+            # the residuals are constants, so the gradient of the sum goes to the skip tensor unchanged
+            assert len(down_residuals) == len(skips)
+            for i, r in enumerate(down_residuals):
+                sk, sg = skips[i]
+                summed = ops.add(sk, r)
+                skips[i] = (summed, sg)
+                if tape is not None:
+                    tape.add(lambda sk=sk, summed=summed: (lambda g: tape.give(sk, g) if g is not None else None)(tape.take(summed)))
         x = self._resnet("mid_block.resnets.0.", x, None, tb_all, geo, tape)
         x = self._spatial("mid_block.attentions.0.", x, text2d, n_text, geo, tape)
         x = self._resnet("mid_block.resnets.1.", x, None, tb_all, geo, tape)
+        if mid_residual is not None:   # :595-598
+            xm = x
+            x = ops.add(xm, mid_residual)
+            if tape is not None:
+                tape.add(lambda xm=xm, xs=x: (lambda g: tape.give(xm, g) if g is not None else None)(tape.take(xs)))
         for i in range(4):
             in_graph = i <= gb
             if not in_graph and only_motion_feature:
@@ -515,11 +529,12 @@ class UNet3DEngine:
         return ["up_blocks.%d.motion_modules.%d.temporal_transformer.transformer_blocks.0.attention_blocks.%d"
                 % (self.guidance_block, j, a) for j in range(L + 1) for a in range(2)]
 
-    def extract_representation(self, noisy_latents, t, uncond_text):
+    def extract_representation(self, noisy_latents, t, uncond_text, down_residuals=None, mid_residual=None):
         """model part of obtain_motion_representation (motionclone_functions.py:74-79): partial forward to the
         guidance block, P = softmax(scale q k^T) of the hooked temporal attentions, top-1 value/index."""
         record = {}
-        self.forward(noisy_latents, t, uncond_text, record=record, only_motion_feature=True)
+        self.forward(noisy_latents, t, uncond_text, record=record, only_motion_feature=True,
+                     down_residuals=down_residuals, mid_residual=mid_residual)
         rep = {}
         for name in self.hooked_names():
             r = record[name]
@@ -535,7 +550,8 @@ class UNet3DEngine:
             out[name] = (idx.to(self.dev, torch.uint8).contiguous(), val.to(self.dev, torch.float32).contiguous())
         return out
 
-    def guided_eps_and_grad(self, latents, t, text_cond, rep_dev, weight, want_loss=False):
+    def guided_eps_and_grad(self, latents, t, text_cond, rep_dev, weight, want_loss=False, down_residuals=None,
+                            mid_residual=None):
         """eps_c forward with the in-graph half taped + backward of  weight * sum_m mse_m  w.r.t. the latent
         (motionclone_functions.py:221-236).  Returns (eps_c tokens, grad fp32 [1,4,F,H,W], loss or None)."""
         tape = Tape()
@@ -544,7 +560,8 @@ class UNet3DEngine:
             numel = idx.numel()
             seeds[name] = (idx, val, self.grad_scale * float(weight) * 2.0 / numel)
         record = {}
-        eps_c = self.forward(latents, t, text_cond, tape=tape, record=record, seeds=seeds)
+        eps_c = self.forward(latents, t, text_cond, tape=tape, record=record, seeds=seeds,
+                             down_residuals=down_residuals, mid_residual=mid_residual)
         loss = None
         if want_loss:
             total = None
@@ -559,3 +576,68 @@ class UNet3DEngine:
         grad = tape.latent_grad
         assert grad is not None, "guidance gradient did not reach the latent"
         return eps_c, grad, loss
+
+
+
+class ControlNetEngine(UNet3DEngine):
+    """SparseControlNetModel.forward (reference motionclone/models/sparse_controlnet.py:450-587) for the
+    configuration of configs/sparsectrl/latent_condition.yaml (BASELINE config 4: i2v_rgb): the noisy input is
+    replaced by zeros (= a broadcast of conv_in.bias, :516-518), the condition is VAE latent + mask through one
+    3x3 conv (:176-184, 522-527), followed by the down blocks (motion modules with a single temporal attention),
+    the mid block and 12 + 1 output 1x1 convs scaled by `conditioning_scale` (:557-574).  Always inference-only
+    (motionclone_functions.py:177)."""
+
+    def _resnet_names(self):
+        L = self.cfg["layers_per_block"]
+        names = []
+        for i in range(4):
+            names += ["down_blocks.%d.resnets.%d." % (i, j) for j in range(L)]
+        return names + ["mid_block.resnets.0.", "mid_block.resnets.1."]
+
+    def forward(self, sample_shape, t, text, cond, mask, conditioning_scale=1.0):
+        """sample_shape = (B, 4, F, H, W); cond [1, Cc, F, H, W] latent condition (zeros on unconditioned frames),
+        mask [1, 1, F, H, W]; text [B, n, dim] -> (list of 12 residual token matrices [(b f y x), C], mid residual)"""
+        cfg, w = self.cfg, self.w
+        if "controlnet_cond_embedding.weight" not in w.sd:
+            raise NotImplementedError("only the simplified (latent) condition embedding of "
+                                      "configs/sparsectrl/latent_condition.yaml is built")
+        B, _, F, H, W = sample_shape
+        L = cfg["layers_per_block"]
+        geo = Geo(B, F, H, W)
+        n_text = text.shape[1]
+        text2d = text.reshape(B * n_text, text.shape[2]).contiguous()
+        tb_all = self._time_bias(t, B, text)
+        cm = torch.cat([cond, mask], dim=1).to(torch.float16)
+        bias = (w.vec("controlnet_cond_embedding.bias") + w.vec("conv_in.bias")).unsqueeze(0).contiguous()
+        e = ops.gemm(ops.latent_to_cl(cm, CIN_PAD), w.conv("controlnet_cond_embedding.weight", CIN_PAD), bias=bias,
+                     mode=CONV_S1, geom=(H, W, H, W), m_out=F * H * W)
+        x = torch.cat([e] * B, dim=0) if B > 1 else e     # the same condition for every batch element
+        feats = [x]
+        for i in range(4):
+            for j in range(L):
+                x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, None)
+                if cfg["down_has_attn"][i]:
+                    x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, None)
+                x = self._motion("down_blocks.%d.motion_modules.%d" % (i, j), x, geo, None, None, None)
+                feats.append(x)
+            if i < 3:
+                x, geo = self._downsample("down_blocks.%d.downsamplers.0.conv." % i, x, geo, None)
+                feats.append(x)
+        x = self._resnet("mid_block.resnets.0.", x, None, tb_all, geo, None)
+        x = self._spatial("mid_block.attentions.0.", x, text2d, n_text, geo, None)
+        x = self._resnet("mid_block.resnets.1.", x, None, tb_all, geo, None)
+        sc = float(conditioning_scale)
+        down = [ops.gemm(f, w.lin("controlnet_down_blocks.%d.weight" % i),
+                         bias=(w.vec("controlnet_down_blocks.%d.bias" % i) * sc).unsqueeze(0).contiguous(), alpha=sc)
+                for i, f in enumerate(feats)]
+        mid = ops.gemm(x, w.lin("controlnet_mid_block.weight"),
+                       bias=(w.vec("controlnet_mid_block.bias") * sc).unsqueeze(0).contiguous(), alpha=sc)
+        return down, mid
+
+
+def split_residuals(down, mid, b, B):
+    """rows of batch element b out of B from every residual (the reference's tensor[[b], ...], :205-208)"""
+    def rows(t):
+        n = t.shape[0] // B
+        return t[b * n:(b + 1) * n]
+    return [rows(d) for d in down], rows(mid)

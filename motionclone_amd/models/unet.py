@@ -184,6 +184,15 @@ class UNet3DConditionModel(nn.Module):
         t = int(timestep) if not torch.is_tensor(timestep) else int(timestep.reshape(-1)[0].item())
         hooked = {n: m for n, m in self.temporal_attentions() if m.processor is not None}
         record = {} if hooked else None
+        def as_tokens(r):   # SparseCtrl residuals: token matrices pass through, reference-layout tensors are converted
+            if r is None or r.dim() == 2:
+                return r
+            if r.dim() == 4:
+                r = r.unsqueeze(2).expand(-1, -1, sample.shape[2], -1, -1)
+            return ops.latent_to_cl(r.to(torch.float16).contiguous(), r.shape[1])
+        if down_block_additional_residuals is not None:
+            down_block_additional_residuals = [as_tokens(r) for r in down_block_additional_residuals]
+            mid_block_additional_residual = as_tokens(mid_block_additional_residual)
         eps = eng.forward(sample.to(torch.float16), t, encoder_hidden_states.to(torch.float16), record=record,
                           only_motion_feature=only_motion_feature,
                           down_residuals=down_block_additional_residuals, mid_residual=mid_block_additional_residual)

@@ -29,8 +29,10 @@ def uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale, num_tr
 
 class MotionCloneSampler:
     def __init__(self, engine, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
-                 num_inference_steps=30, guidance_steps=18, guidance_scale=0.4, score_guidance_scale=1.0):
+                 num_inference_steps=30, guidance_steps=18, guidance_scale=0.4, score_guidance_scale=1.0,
+                 controlnet=None):
         self.engine = engine
+        self.controlnet = controlnet     # ControlNetEngine or None (image-to-video, SparseCtrl)
         self.cfg_scale = float(cfg_scale)
         self.weight = float(motion_guidance_weight)
         self.warm, self.cool = warm_up_steps, cool_up_steps
@@ -61,32 +63,49 @@ class MotionCloneSampler:
         a = float(self.acp[int(t)])
         return (a ** 0.5 * x0.float() + (1 - a) ** 0.5 * noise.float()).to(x0.dtype)
 
-    def extract(self, video_latents, noise, uncond_text, add_noise_step=400):
+    def extract(self, video_latents, noise, uncond_text, add_noise_step=400, ctrl=None):
+        """ctrl = dict(cond, mask, scale) runs the SparseCtrl encoder first (motionclone_functions.py:46-72)"""
         noisy = self.add_noise(add_noise_step, video_latents, noise)
-        return self.engine.extract_representation(noisy, add_noise_step, uncond_text)
+        if ctrl is None:
+            return self.engine.extract_representation(noisy, add_noise_step, uncond_text)
+        down, mid = self.controlnet.forward(tuple(noisy.shape), add_noise_step, uncond_text, ctrl["cond"], ctrl["mask"],
+                                            ctrl.get("scale", 1.0))
+        return self.engine.extract_representation(noisy, add_noise_step, uncond_text, down_residuals=down,
+                                                  mid_residual=mid)
 
-    def step(self, latents, i, text, rep_dev, aux=None):
-        """single_step_video (motionclone_functions.py:173-257): text = [uncond, cond] embeddings [2, n, dim]"""
+    def step(self, latents, i, text, rep_dev, aux=None, ctrl=None):
+        """single_step_video (motionclone_functions.py:173-257): text = [uncond, cond] embeddings [2, n, dim];
+        ctrl = dict(cond, mask, scale) enables the SparseCtrl pass of :176-197 (one B=2 encoder run per step)"""
+        from .engine import split_residuals
         eng = self.engine
         t, a_t, a_prev = self._alphas(i)
+        down = mid = None
+        if ctrl is not None:
+            shape2 = (2,) + tuple(latents.shape[1:])
+            down, mid = self.controlnet.forward(shape2, t, text, ctrl["cond"], ctrl["mask"], ctrl.get("scale", 1.0))
         if i < self.G:
-            eps_u = eng.forward(latents, t, text[0:1])
+            du = mu = dc = mc = None
+            if down is not None:
+                du, mu = split_residuals(down, mid, 0, 2)
+                dc, mc = split_residuals(down, mid, 1, 2)
+            eps_u = eng.forward(latents, t, text[0:1], down_residuals=du, mid_residual=mu)
             w = self.weight * self.guidance_factor(i)
-            eps_c, grad, loss = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w, want_loss=aux is not None)
+            eps_c, grad, loss = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w, want_loss=aux is not None,
+                                                        down_residuals=dc, mid_residual=mc)
             if aux is not None:
                 aux.update(eps_u=eps_u, eps_c=eps_c, grad=grad, loss=loss)
             coef = self.score_gs * (1.0 - a_t) ** 0.5
             return ops.cfg_ddim_step(eps_c, eps_u, latents, grad, self.cfg_scale, a_t, a_prev, coef)
-        eps2 = eng.forward(latents.expand(2, -1, -1, -1, -1), t, text)
+        eps2 = eng.forward(latents.expand(2, -1, -1, -1, -1), t, text, down_residuals=down, mid_residual=mid)
         T1 = eps2.shape[0] // 2
         if aux is not None:
             aux.update(eps_u=eps2[:T1], eps_c=eps2[T1:])
         return ops.cfg_ddim_step(eps2[T1:], eps2[:T1], latents, None, self.cfg_scale, a_t, a_prev, 0.0)
 
-    def sample(self, latents, text, rep, progress=None):
+    def sample(self, latents, text, rep, progress=None, ctrl=None):
         rep_dev = self.engine.prepare_representation(rep)
         for i in range(len(self.timesteps)):
-            latents = self.step(latents, i, text, rep_dev)
+            latents = self.step(latents, i, text, rep_dev, ctrl=ctrl)
             if progress is not None:
                 progress(i)
         return latents

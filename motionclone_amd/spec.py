@@ -121,6 +121,67 @@ def param_shapes(cfg):
     return s
 
 
+def controlnet_param_shapes(cfg, conditioning_channels=4):
+    """reference SparseControlNetModel keys (sparse_controlnet.py:150-314), latent-condition configuration"""
+    ch = cfg["block_out_channels"]
+    temb, xdim, L = ch[0] * 4, cfg["cross_attention_dim"], cfg["layers_per_block"]
+    s = OrderedDict()
+    s["conv_in.weight"] = (ch[0], cfg["in_channels"], 3, 3)
+    s["conv_in.bias"] = (ch[0],)
+    s["controlnet_cond_embedding.weight"] = (ch[0], conditioning_channels + 1, 3, 3)
+    s["controlnet_cond_embedding.bias"] = (ch[0],)
+    s["time_embedding.linear_1.weight"] = (temb, ch[0])
+    s["time_embedding.linear_1.bias"] = (temb,)
+    s["time_embedding.linear_2.weight"] = (temb, temb)
+    s["time_embedding.linear_2.bias"] = (temb,)
+    outs = [ch[0]]
+    out = ch[0]
+    for i in range(4):
+        cin, out = out, ch[i]
+        for j in range(L):
+            _res(s, "down_blocks.%d.resnets.%d." % (i, j), cin if j == 0 else out, out, temb)
+            if cfg["down_has_attn"][i]:
+                _spatial(s, "down_blocks.%d.attentions.%d." % (i, j), out, xdim)
+            mm = OrderedDict()
+            _motion(mm, "down_blocks.%d.motion_modules.%d." % (i, j), out)
+            s.update((k, v) for k, v in mm.items() if "attention_blocks.1." not in k and "norms.1." not in k)
+            outs.append(out)
+        if i < 3:
+            s["down_blocks.%d.downsamplers.0.conv.weight" % i] = (out, out, 3, 3)
+            s["down_blocks.%d.downsamplers.0.conv.bias" % i] = (out,)
+            outs.append(out)
+    for i, c in enumerate(outs):
+        s["controlnet_down_blocks.%d.weight" % i] = (c, c, 1, 1)
+        s["controlnet_down_blocks.%d.bias" % i] = (c,)
+    c = ch[-1]
+    _res(s, "mid_block.resnets.0.", c, c, temb)
+    _spatial(s, "mid_block.attentions.0.", c, xdim)
+    _res(s, "mid_block.resnets.1.", c, c, temb)
+    s["controlnet_mid_block.weight"] = (c, c, 1, 1)
+    s["controlnet_mid_block.bias"] = (c,)
+    return s
+
+
+def synthetic_controlnet_state_dict(cfg, seed=4321, device="cuda", dtype=torch.float16):
+    """seeded random SparseCtrl weights (zero-initialised layers get small random values, see synthetic_state_dict)"""
+    shapes = controlnet_param_shapes(cfg)
+    g = torch.Generator(device=device).manual_seed(seed)
+    sd = OrderedDict()
+    for name, shape in shapes.items():
+        if len(shape) == 1 and "norm" in name:
+            t = (1.0 if name.endswith("weight") else 0.0) + 0.05 * torch.randn(shape, generator=g, device=device)
+        elif "temporal_transformer.proj_out" in name:
+            t = 0.02 * torch.randn(shape, generator=g, device=device)
+        else:
+            wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shape
+            fan_in = 1
+            for d in wshape[1:]:
+                fan_in *= d
+            t = (torch.rand(shape, generator=g, device=device) * 2 - 1) / math.sqrt(fan_in)
+        sd[name] = t.to(dtype)
+    return sd
+
+
 def synthetic_state_dict(cfg, seed=1234, device="cuda", dtype=torch.float16, flat=None):
     """Seeded random-init weights of the named architecture (no checkpoints exist offline; BASELINE.json asks for
     synthetic data).  fan-in-uniform conv/linear weights as PyTorch's default init, unit norms, and motion

@@ -58,8 +58,6 @@ def _sampler(pipe):
 def obtain_motion_representation(self, generator=None, motion_representation_path: str = None, duration=None,
                                  use_controlnet=False, video_latents=None, uncond_embeddings=None):
     """:25-82.  `video_latents` / `uncond_embeddings` let synthetic inputs bypass decord / VAE / CLIP."""
-    if use_controlnet:
-        raise NotImplementedError("SparseCtrl (i2v) is scheduled after the t2v path (SURVEY.md 8a A16)")
     cfg = self.input_config
     if video_latents is None:
         video_data = video_preprocess(cfg.video_path, cfg.height, cfg.width, cfg.video_length, duration=duration)
@@ -71,9 +69,19 @@ def obtain_motion_representation(self, generator=None, motion_representation_pat
     step_t = int(cfg.add_noise_step)
     noise = torch.randn(video_latents.shape, generator=generator, device=video_latents.device, dtype=video_latents.dtype)
     noisy = self.add_noise(step_t, video_latents, noise)
+    down_res = mid_res = None
+    if use_controlnet:   # :46-72: condition = the reference video's own latent at image_index (simplified embedding)
+        idx = cfg.image_index
+        cond = torch.zeros_like(video_latents)
+        mask = torch.zeros_like(video_latents[:, :1])
+        cond[:, :, idx] = video_latents[:, :, idx]
+        mask[:, :, idx] = 1
+        down_res, mid_res = self.controlnet(noisy, step_t, encoder_hidden_states=uncond_embeddings, controlnet_cond=cond,
+                                            conditioning_mask=mask, conditioning_scale=cfg.controlnet_scale,
+                                            guess_mode=False, return_dict=False)
     # partial forward up to the guidance block; the hooked attentions record their q / k (:74-76)
     self.unet(noisy.half(), step_t, encoder_hidden_states=uncond_embeddings.half(), return_dict=False,
-              only_motion_feature=True)
+              only_motion_feature=True, down_block_additional_residuals=down_res, mid_block_additional_residual=mid_res)
     rep = {}
     for name, module in self.unet.named_modules():
         if "VersatileAttention" in type(module).__name__ and classify_blocks(cfg.motion_guidance_blocks, name):
@@ -120,23 +128,42 @@ def compute_temp_loss(self, temp_attn_prob_control_dict):
 
 def single_step_video(self, noisy_latents, step_index, step_t, extra_step_kwargs):
     """:173-257 (guided branch while step_index < guidance_steps, else one B=2 forward)"""
-    if getattr(self, "add_controlnet", False):
-        raise NotImplementedError("SparseCtrl (i2v) is scheduled after the t2v path (SURVEY.md 8a A16)")
     smp = _sampler(self)
+    ctrl = None
+    if getattr(self, "add_controlnet", False):   # :176-197: condition latents placed at image_index, mask = 1 there
+        smp.controlnet = self.controlnet.engine()
+        ci = self.controlnet_images.to(noisy_latents.device, torch.float16)
+        shape = list(ci.shape)
+        shape[2] = noisy_latents.shape[2]
+        cond = torch.zeros(shape, device=ci.device, dtype=ci.dtype)
+        mask = torch.zeros([shape[0], 1] + shape[2:], device=ci.device, dtype=ci.dtype)
+        cond[:, :, self.input_config.image_index] = ci
+        mask[:, :, self.input_config.image_index] = 1
+        ctrl = dict(cond=cond, mask=mask, scale=self.input_config.controlnet_scale)
     if getattr(self, "_mc_rep_src", None) is not self.motion_representation_dict:
         self._mc_rep_dev = smp.engine.prepare_representation(self.motion_representation_dict)
         self._mc_rep_src = self.motion_representation_dict
-    out = smp.step(noisy_latents.half(), step_index, self.text_embeddings.half(), self._mc_rep_dev)
+    out = smp.step(noisy_latents.half(), step_index, self.text_embeddings.half(), self._mc_rep_dev, ctrl=ctrl)
     return out.detach()
 
 
 def sample_video(self, eta: float = 0.0, generator=None, noisy_latents: Optional[torch.Tensor] = None,
-                 add_controlnet: bool = False, text_embeddings=None, decode=True):
+                 add_controlnet: bool = False, text_embeddings=None, decode=True, controlnet_images=None):
     """:102-171"""
     self.add_controlnet = add_controlnet
-    if add_controlnet:
-        raise NotImplementedError("SparseCtrl (i2v) is scheduled after the t2v path (SURVEY.md 8a A16)")
     cfg = self.input_config
+    if add_controlnet and controlnet_images is not None:
+        self.controlnet_images = controlnet_images      # already VAE latents [1, 4, n_images, h, w] (:122-126)
+    elif add_controlnet:
+        from PIL import Image
+        import numpy as _np
+        imgs = []
+        for path in cfg.condition_image_path_list:       # :112-119 (Resize + ToTensor), then VAE encode (:121-126)
+            im = Image.open(path).convert("RGB").resize((cfg.width, cfg.height), Image.BILINEAR)
+            imgs.append(torch.from_numpy(_np.asarray(im)).permute(2, 0, 1).float() / 255.0)
+        px = torch.stack(imgs).to(dtype=self.vae.dtype, device=self.vae.device)
+        lat = self.vae.encode(px * 2.0 - 1.0).latent_dist.sample() * self.vae.config.scaling_factor
+        self.controlnet_images = lat.unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
     device = self._execution_device
     if text_embeddings is None:
         text_embeddings = self._encode_prompt(cfg.new_prompt, device, 1, True, cfg.negative_prompt)

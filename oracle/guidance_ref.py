@@ -106,7 +106,7 @@ def extract_representation(sd, cfg, video_latents, noise, uncond_text, add_noise
         return motion_representation(temp_attn_prob(rec, cfg["motion_heads"]))
 
 
-def guided_step(sd, cfg, latents, step_index, timesteps, text, rep, hp, guidance_block=1):
+def guided_step(sd, cfg, latents, step_index, timesteps, text, rep, hp, guidance_block=1, res_u=None, res_c=None):
     """single_step_video, guided branch (motionclone_functions.py:200-243).
     hp: dict(cfg_scale, motion_guidance_weight, guidance_steps, warm_up_steps, cool_up_steps).
     Returns (next latents, dict of intermediates for parity checks)."""
@@ -115,9 +115,11 @@ def guided_step(sd, cfg, latents, step_index, timesteps, text, rep, hp, guidance
     hooked = ("up_blocks.%d" % guidance_block,)
     control = latents.clone().detach().requires_grad_(True)
     with torch.no_grad():
-        eps_u = U.unet_forward(sd, cfg, latents, t, text[[0]], guidance_block=guidance_block)
+        eps_u = U.unet_forward(sd, cfg, latents, t, text[[0]], guidance_block=guidance_block,
+                               down_residuals=res_u[0] if res_u else None, mid_residual=res_u[1] if res_u else None)
     rec = {}
-    eps_c = U.unet_forward(sd, cfg, control, t, text[[1]], guidance_block=guidance_block, record=rec, hooked=hooked)
+    eps_c = U.unet_forward(sd, cfg, control, t, text[[1]], guidance_block=guidance_block, record=rec, hooked=hooked,
+                           down_residuals=res_c[0] if res_c else None, mid_residual=res_c[1] if res_c else None)
     prob = temp_attn_prob(rec, cfg["motion_heads"])
     loss = hp["motion_guidance_weight"] * temp_loss(prob, rep)
     loss = loss * guidance_scale_factor(step_index, hp["guidance_steps"], hp["warm_up_steps"], hp["cool_up_steps"])
@@ -127,17 +129,18 @@ def guided_step(sd, cfg, latents, step_index, timesteps, text, rep, hp, guidance
     return nxt.detach(), dict(eps_u=eps_u.detach(), eps_c=eps_c.detach(), loss=loss.detach(), grad=grad.detach())
 
 
-def plain_step(sd, cfg, latents, step_index, timesteps, text):
+def plain_step(sd, cfg, latents, step_index, timesteps, text, res=None):
     """single_step_video, un-guided branch: one B=2 UNet call on expanded latents (:245-257)."""
     acp = alphas_cumprod()
     t = int(timesteps[step_index])
     with torch.no_grad():
-        eps2 = U.unet_forward(sd, cfg, latents.expand(2, -1, -1, -1, -1), t, text)
+        eps2 = U.unet_forward(sd, cfg, latents.expand(2, -1, -1, -1, -1), t, text,
+                              down_residuals=res[0] if res else None, mid_residual=res[1] if res else None)
     return eps2, acp
 
 
-def plain_step_full(sd, cfg, latents, step_index, timesteps, text, cfg_scale):
-    eps2, acp = plain_step(sd, cfg, latents, step_index, timesteps, text)
+def plain_step_full(sd, cfg, latents, step_index, timesteps, text, cfg_scale, res=None):
+    eps2, acp = plain_step(sd, cfg, latents, step_index, timesteps, text, res)
     eps = eps2[[1]] + cfg_scale * (eps2[[1]] - eps2[[0]])      # :255
     nxt = ddim_step(acp, timesteps, step_index, eps, latents, score=None)
     return nxt, dict(eps_u=eps2[[0]], eps_c=eps2[[1]])

@@ -388,3 +388,121 @@ def unet_forward(sd, cfg, sample, timestep, text, guidance_block=1, only_motion_
                 x = up_block(i, x)
     x = Fn.silu(_gn(sd, "conv_norm_out.", x, cfg["norm_num_groups"], cfg["norm_eps"]))
     return _conv(sd, "conv_out.", x)
+
+
+# ---- SparseCtrl (image-to-video conditioning encoder) ------------------------------------------------------
+def controlnet_param_shapes(cfg, conditioning_channels=4):
+    """Parameters of the reference SparseControlNetModel (sparse_controlnet.py:150-314) in the configuration of
+    configs/sparsectrl/latent_condition.yaml: simplified condition embedding (one 3x3 conv on latent + mask),
+    motion modules with a single Temporal_Self attention, 12 + 1 zero-initialised 1x1 output convs."""
+    ch = cfg["block_out_channels"]
+    temb, xdim, L = ch[0] * 4, cfg["cross_attention_dim"], cfg["layers_per_block"]
+    s = OrderedDict()
+    s["conv_in.weight"] = (ch[0], cfg["in_channels"], 3, 3)
+    s["conv_in.bias"] = (ch[0],)
+    s["controlnet_cond_embedding.weight"] = (ch[0], conditioning_channels + 1, 3, 3)
+    s["controlnet_cond_embedding.bias"] = (ch[0],)
+    s["time_embedding.linear_1.weight"] = (temb, ch[0])
+    s["time_embedding.linear_1.bias"] = (temb,)
+    s["time_embedding.linear_2.weight"] = (temb, temb)
+    s["time_embedding.linear_2.bias"] = (temb,)
+    n_out = 0
+
+    def zero_conv(c):
+        nonlocal n_out
+        s["controlnet_down_blocks.%d.weight" % n_out] = (c, c, 1, 1)
+        s["controlnet_down_blocks.%d.bias" % n_out] = (c,)
+        n_out += 1
+    zero_conv(ch[0])
+    out = ch[0]
+    for i in range(4):
+        cin, out = out, ch[i]
+        for j in range(L):
+            s.update(_resnet_shapes("down_blocks.%d.resnets.%d." % (i, j), cin if j == 0 else out, out, temb))
+            if cfg["down_has_attn"][i]:
+                s.update(_spatial_shapes("down_blocks.%d.attentions.%d." % (i, j), out, xdim))
+            mm = _motion_shapes("down_blocks.%d.motion_modules.%d." % (i, j), out)
+            s.update(OrderedDict((k, v) for k, v in mm.items() if "attention_blocks.1." not in k and "norms.1." not in k))
+            zero_conv(out)
+        if i < 3:
+            s["down_blocks.%d.downsamplers.0.conv.weight" % i] = (out, out, 3, 3)
+            s["down_blocks.%d.downsamplers.0.conv.bias" % i] = (out,)
+            zero_conv(out)
+    c = ch[-1]
+    s.update(_resnet_shapes("mid_block.resnets.0.", c, c, temb))
+    s.update(_spatial_shapes("mid_block.attentions.0.", c, xdim))
+    s.update(_resnet_shapes("mid_block.resnets.1.", c, c, temb))
+    s["controlnet_mid_block.weight"] = (c, c, 1, 1)
+    s["controlnet_mid_block.bias"] = (c,)
+    return s
+
+
+def random_controlnet_state_dict(cfg, seed=4321, conditioning_channels=4):
+    """Seeded synthetic SparseCtrl weights; the zero-initialised layers (cond embedding, output convs, motion
+    proj_out) get small random values instead, otherwise the encoder's output would be identically zero."""
+    g = torch.Generator().manual_seed(seed)
+    shapes = controlnet_param_shapes(cfg, conditioning_channels)
+    sd = OrderedDict()
+    for name, shape in shapes.items():
+        if "norm" in name and len(shape) == 1:
+            t = (torch.ones(shape) if name.endswith("weight") else torch.zeros(shape)) + 0.05 * torch.randn(shape, generator=g)
+        elif "temporal_transformer.proj_out" in name:
+            t = 0.02 * torch.randn(shape, generator=g)
+        else:
+            wshape = shapes[name[:-4] + "weight"] if name.endswith("bias") else shape
+            fan_in = 1
+            for d in wshape[1:]:
+                fan_in *= d
+            t = (torch.rand(shape, generator=g) * 2 - 1) / math.sqrt(fan_in)
+        sd[name] = t
+    return sd
+
+
+def motion_module_single(sd, p, x, cfg):
+    """the SparseCtrl flavour of VanillaTemporalModule: attention_block_types = ['Temporal_Self'] (one attention)"""
+    B, C, F, H, W = x.shape
+    heads = cfg["motion_heads"]
+    p = p + "temporal_transformer."
+    h = _gn(sd, p + "norm.", x, cfg["norm_num_groups"], 1e-6)
+    tok = _lin(sd, p + "proj_in.", h.permute(0, 2, 3, 4, 1).reshape(B * F, H * W, C))
+    b = p + "transformer_blocks.0."
+    pe = temporal_pe(cfg["motion_pe_max_len"], C, x.device).to(x.dtype)
+    N = H * W
+    n = _ln(sd, b + "norms.0.", tok)
+    seq = n.reshape(B, F, N, C).permute(0, 2, 1, 3).reshape(B * N, F, C) + pe[None, :F]
+    ap = b + "attention_blocks.0."
+    o = _lin(sd, ap + "to_out.0.", _mha(_lin(sd, ap + "to_q.", seq), _lin(sd, ap + "to_k.", seq), _lin(sd, ap + "to_v.", seq), heads))
+    tok = o.reshape(B, N, F, C).permute(0, 2, 1, 3).reshape(B * F, N, C) + tok
+    tok = _feed_forward(sd, b + "ff.", _ln(sd, b + "ff_norm.", tok)) + tok
+    tok = _lin(sd, p + "proj_out.", tok)
+    return tok.reshape(B, F, H, W, C).permute(0, 4, 1, 2, 3) + x
+
+
+def controlnet_forward(sd, cfg, sample_shape, timestep, text, cond, mask, conditioning_scale=1.0):
+    """SparseControlNetModel.forward (sparse_controlnet.py:450-587) with set_noisy_sample_input_to_zero = True and
+    use_simplified_condition_embedding = True: returns (12 down residuals, mid residual), each scaled."""
+    B, _, F, H, W = sample_shape
+    L = cfg["layers_per_block"]
+    t = torch.as_tensor(timestep, device=text.device).reshape(-1).expand(B)
+    temb = timestep_embedding(sd, t, cfg["block_out_channels"][0], text.dtype)
+    x = sd["conv_in.bias"].reshape(1, -1, 1, 1, 1).expand(B, -1, F, H, W)                     # :516-518
+    emb = _conv({"weight": sd["controlnet_cond_embedding.weight"], "bias": sd["controlnet_cond_embedding.bias"]}, "",
+                torch.cat([cond, mask], dim=1))                                               # :522-525
+    x = x + emb
+    feats = [x]
+    for i in range(4):
+        for j in range(L):
+            x = resnet_block(sd, "down_blocks.%d.resnets.%d." % (i, j), x, temb, cfg)
+            if cfg["down_has_attn"][i]:
+                x = spatial_transformer(sd, "down_blocks.%d.attentions.%d." % (i, j), x, text, cfg)
+            x = motion_module_single(sd, "down_blocks.%d.motion_modules.%d." % (i, j), x, cfg)
+            feats.append(x)
+        if i < 3:
+            x = _conv(sd, "down_blocks.%d.downsamplers.0.conv." % i, x, stride=2)
+            feats.append(x)
+    x = resnet_block(sd, "mid_block.resnets.0.", x, temb, cfg)
+    x = spatial_transformer(sd, "mid_block.attentions.0.", x, text, cfg)
+    x = resnet_block(sd, "mid_block.resnets.1.", x, temb, cfg)
+    down = [_conv(sd, "controlnet_down_blocks.%d." % i, f, pad=0) * conditioning_scale for i, f in enumerate(feats)]
+    mid = _conv(sd, "controlnet_mid_block.", x, pad=0) * conditioning_scale
+    return down, mid

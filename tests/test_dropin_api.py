@@ -106,3 +106,54 @@ def test_motionclone_alias_package_exports_reference_names():
             "print('ok')\n") % __import__("os").path.dirname(__import__("os").path.dirname(__file__))
     r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr
+
+
+def test_i2v_flow_with_sparsectrl_matches_oracle(backend):
+    """i2v_video_sample.py flow: SparseControlNetModel.from_unet + add_controlnet sampling vs the oracle loop"""
+    from motionclone_amd.models.sparse_controlnet import SparseControlNetModel
+    dev = backend
+    cfg = dict(U.TINY_CONFIG)
+    sd = {k: v.half().float() for k, v in U.random_state_dict(cfg, seed=1234).items()}
+    csd = {k: v.half().float() for k, v in U.random_controlnet_state_dict(cfg).items()}
+    N, Gs, gscale = 3, 2, 0.3
+    pipe = build_pipeline(dev, cfg, sd, N, Gs, gscale)
+    ckw = dict(set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+               use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
+               motion_module_type="Vanilla",
+               motion_module_kwargs=dict(num_attention_heads=cfg["motion_heads"], num_transformer_block=1,
+                                         attention_block_types=["Temporal_Self"], temporal_position_encoding=True,
+                                         temporal_position_encoding_max_len=32, temporal_attention_dim_div=1))
+    controlnet = SparseControlNetModel.from_unet(pipe.unet, controlnet_additional_kwargs=ckw)
+    assert set(controlnet.state_dict().keys()) == set(csd.keys())
+    controlnet.load_state_dict(csd)
+    pipe.controlnet = controlnet.to(dev).to(dtype=torch.float16)
+    pipe.input_config.image_index = [0]
+    pipe.input_config.controlnet_scale = 0.8
+
+    text = torch.randn(2, 7, cfg["cross_attention_dim"], generator=torch.Generator().manual_seed(7)).half()
+    vid = (0.18215 * torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(11))).half()
+    img_lat = (0.18215 * torch.randn(1, 4, 1, 8, 8, generator=torch.Generator().manual_seed(12))).half()
+    rep = pipe.obtain_motion_representation(generator=torch.Generator(device=dev).manual_seed(5), use_controlnet=True,
+                                            video_latents=vid.to(dev), uncond_embeddings=text[0:1].to(dev))
+    lat0 = torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(2025)).half()
+    out = pipe.sample_video(noisy_latents=lat0.to(dev), text_embeddings=text.to(dev), decode=False, add_controlnet=True,
+                            controlnet_images=img_lat.to(dev))
+    # oracle loop with the same representation and per-step encoder residuals
+    rep_cpu = {k: [a.float().cpu(), b.cpu()] for k, (a, b) in rep.items()}
+    cond = torch.zeros(1, 4, 4, 8, 8)
+    mask = torch.zeros(1, 1, 4, 8, 8)
+    cond[:, :, [0]] = img_lat.float()
+    mask[:, :, [0]] = 1
+    ts = G.uneven_timesteps(N, Gs, gscale)
+    hp = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10, guidance_steps=Gs)
+    x = lat0.float()
+    for i in range(N):
+        with torch.no_grad():
+            d, m = U.controlnet_forward(csd, cfg, (2, 4, 4, 8, 8), int(ts[i]), text.float(), cond, mask, 0.8)
+        if i < Gs:
+            x, _ = G.guided_step(sd, cfg, x, i, ts, text.float(), rep_cpu, hp, res_u=([t[[0]] for t in d], m[[0]]),
+                                 res_c=([t[[1]] for t in d], m[[1]]))
+        else:
+            x, _ = G.plain_step_full(sd, cfg, x, i, ts, text.float(), 7.5, res=(d, m))
+    err = ((out.float().cpu() - x).norm() / x.norm()).item()
+    assert err < 3e-2, err
