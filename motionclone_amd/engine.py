@@ -134,10 +134,11 @@ class Weights:
 class Tape:
     """reverse schedule: closures appended in forward order, run backwards; grads keyed by tensor identity"""
 
-    def __init__(self):
+    def __init__(self, grad_batch=None):
         self.fns = []
         self.grads = {}
         self.keep = []
+        self.grad_batch = grad_batch   # differentiate only this batch element of a B > 1 forward (None: all)
 
     def add(self, fn):
         self.fns.append(fn)
@@ -209,6 +210,29 @@ class UNet3DEngine:
         allp = ops.gemm(ops.silu(e), self.temb_w)
         return (allp.float() + self.temb_b.unsqueeze(0)).contiguous()
 
+    # ---- batch slicing for the backward ------------------------------------------------------------------
+    @staticmethod
+    def _bslice(geo, b):
+        """The forward may run B = 2 (uncond | cond) while only batch element `b` is differentiated (the reference
+        runs them as two B = 1 calls, motionclone_functions.py:216-223 - per-sample results are identical).  Returns
+        the B = 1 geometry and a function that cuts batch b out of any saved per-token / per-frame / per-batch tensor;
+        token order is batch-major, so every slice is a contiguous row range (a view)."""
+        if b is None:
+            return geo, (lambda t: t)
+        T1 = geo.T // geo.B
+
+        def cut(t):
+            if t is None:
+                return None
+            n = t.shape[0]
+            if n == geo.T:
+                return t[b * T1:(b + 1) * T1]
+            if n == geo.frames:
+                return t[b * geo.F:(b + 1) * geo.F]
+            per = n // geo.B          # per-batch rows (text keys/values, time bias)
+            return t[b * per:(b + 1) * per]
+        return Geo(1, geo.F, geo.H, geo.W), cut
+
     # ---- modules -----------------------------------------------------------------------------------
     def _resnet(self, p, x, x2, tb_all, geo, tape):
         """ResnetBlock3D.forward (resnet.py:183-213); x2 = skip tensor of the up-block concat or None"""
@@ -217,10 +241,10 @@ class UNet3DEngine:
         fr, hw, H, W = geo.frames, geo.hw, geo.H, geo.W
         off, cout = self.temb_off[p]
         tb = tb_all[:, off:off + cout].contiguous()
-        g1, b1 = w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias")
+        g1w, b1 = w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias")
         g2, b2 = w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias")
         st1 = ops.gn_stats(x, x2, fr, hw, eps)
-        h1 = ops.gn_apply(x, x2, st1, g1, b1, True, fr, hw)
+        h1 = ops.gn_apply(x, x2, st1, g1w, b1, True, fr, hw)
         h2 = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=geo.F * hw, mode=CONV_S1,
                       geom=(H, W, H, W), m_out=geo.T)
         del h1
@@ -236,18 +260,22 @@ class UNet3DEngine:
         out = ops.gemm(h3, w.conv(p + "conv2.weight"), bias=w.vec(p + "conv2.bias").unsqueeze(0), residual=sc,
                        mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
         if tape is not None:
+            g1, cut = self._bslice(geo, tape.grad_batch)
+            bx, bx2, bst1, bh2, bst2 = cut(x), cut(x2), cut(st1), cut(h2), cut(st2)
+            H1, W1, fr1, hw1 = g1.H, g1.W, g1.frames, g1.hw
+
             def bwd():
                 dout = tape.take(out)
                 if dout is None:
                     return
-                dh3 = ops.gemm(dout, w.conv_dgrad(p + "conv2.weight"), mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
-                dh2 = ops.gn_bwd(h2, None, dh3, st2, g2, b2, True, fr, hw)
-                dh1 = ops.gemm(dh2, w.conv_dgrad(p + "conv1.weight"), mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
+                dh3 = ops.gemm(dout, w.conv_dgrad(p + "conv2.weight"), mode=CONV_S1, geom=(H1, W1, H1, W1), m_out=g1.T)
+                dh2 = ops.gn_bwd(bh2, None, dh3, bst2, g2, b2, True, fr1, hw1)
+                dh1 = ops.gemm(dh2, w.conv_dgrad(p + "conv1.weight"), mode=CONV_S1, geom=(H1, W1, H1, W1), m_out=g1.T)
                 if has_sc:
-                    dx = ops.gn_bwd(x, x2, dh1, st1, g1, b1, True, fr, hw)
+                    dx = ops.gn_bwd(bx, bx2, dh1, bst1, g1w, b1, True, fr1, hw1)
                     ops.gemm(dout, w.lin_t(p + "conv_shortcut.weight"), residual=dx, out=dx)
                 else:
-                    dx = ops.gn_bwd(x, None, dh1, st1, g1, b1, True, fr, hw, out=dout, accumulate=True)
+                    dx = ops.gn_bwd(bx, None, dh1, bst1, g1w, b1, True, fr1, hw1, out=dout, accumulate=True)
                 c1 = x.shape[1]
                 if x2 is None:
                     tape.give(x, dx)
@@ -302,28 +330,34 @@ class UNet3DEngine:
         if tape is None:
             return out
 
+        g1, cut = self._bslice(geo, tape.grad_batch)
+        bx, bst, bh0, bh1, bh2 = cut(x), cut(st), cut(h0), cut(h1), cut(h2)
+        bls1, bls2, bls3, bqkv, ba1, blse1 = cut(ls1), cut(ls2), cut(ls3), cut(qkv), cut(a1), cut(lse1)
+        bq2, bkv, ba2, blse2, bff1 = cut(q2), cut(kv), cut(a2), cut(lse2), cut(ff1)
+        fr1, hw1, T1 = g1.frames, g1.hw, g1.T
+
         def bwd():
             dout = tape.take(out)
             if dout is None:
                 return
             dh3 = ops.gemm(dout, w.lin_t(p + "proj_out.weight"))
             dg = ops.gemm(dh3, w.lin_t(b + "ff.net.2.weight"))
-            dff1 = ops.geglu_bwd(dg, ff1)
+            dff1 = ops.geglu_bwd(dg, bff1)
             dn3 = ops.gemm(dff1, w.lin_t(b + "ff.net.0.proj.weight"))
-            dh2 = ops.layernorm_bwd(dn3, h2, ls3, w.vec(b + "norm3.weight"), add=dh3)
+            dh2 = ops.layernorm_bwd(dn3, bh2, bls3, w.vec(b + "norm3.weight"), add=dh3)
             da2 = ops.gemm(dh2, w.lin_t(b + "attn2.to_out.0.weight"))
-            dq2, _, _ = ops.attn_bwd(q2, kv[:, :C], kv[:, C:], a2, da2, lse2, hw, n_text, heads, d, fr,
-                                     kv_bdiv=geo.F, need_dkv=False)
+            dq2, _, _ = ops.attn_bwd(bq2, bkv[:, :C], bkv[:, C:], ba2, da2, blse2, hw1, n_text, heads, d, fr1,
+                                     kv_bdiv=g1.F, need_dkv=False)
             dn2 = ops.gemm(dq2, w.lin_t(b + "attn2.to_q.weight"))
-            dh1 = ops.layernorm_bwd(dn2, h1, ls2, w.vec(b + "norm2.weight"), add=dh2)
+            dh1 = ops.layernorm_bwd(dn2, bh1, bls2, w.vec(b + "norm2.weight"), add=dh2)
             da1 = ops.gemm(dh1, w.lin_t(b + "attn1.to_out.0.weight"))
-            dqkv = ops.empty((T, 3 * C), x)
-            ops.attn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], a1, da1, lse1, hw, hw, heads, d, fr,
+            dqkv = ops.empty((T1, 3 * C), x)
+            ops.attn_bwd(bqkv[:, :C], bqkv[:, C:2 * C], bqkv[:, 2 * C:], ba1, da1, blse1, hw1, hw1, heads, d, fr1,
                          dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
             dn1 = ops.gemm(dqkv, w.cat_lin_t([b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"]))
-            dh0 = ops.layernorm_bwd(dn1, h0, ls1, w.vec(b + "norm1.weight"), add=dh1)
+            dh0 = ops.layernorm_bwd(dn1, bh0, bls1, w.vec(b + "norm1.weight"), add=dh1)
             dhn = ops.gemm(dh0, w.lin_t(p + "proj_in.weight"))
-            dx = ops.gn_bwd(x, None, dhn, st, gN, bN, False, fr, hw, out=dout, accumulate=True)
+            dx = ops.gn_bwd(bx, None, dhn, bst, gN, bN, False, fr1, hw1, out=dout, accumulate=True)
             tape.give(x, dx)
         tape.add(bwd)
         return out
@@ -354,8 +388,9 @@ class UNet3DEngine:
                                       save_stats=tape is not None)
             qkv = ops.gemm(n, w.cat_lin([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]))
             del n
-            if record is not None:
-                record[aname] = dict(qkv=qkv, C=C, heads=heads, d=d, geo=geo)
+            if record is not None:   # the guidance read-out sees the differentiated batch element only
+                rg, rcut = self._bslice(geo, tape.grad_batch if tape is not None else None)
+                record[aname] = dict(qkv=rcut(qkv), C=C, heads=heads, d=d, geo=rg)
             o = ops.tattn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], geo.B, geo.F, hw, heads, d)
             hnext = ops.gemm(o, w.lin(ap + "to_out.0.weight"), bias=w.vec(ap + "to_out.0.bias").unsqueeze(0), residual=h)
             saved.append((h, ls, qkv, aname, ap))
@@ -375,36 +410,41 @@ class UNet3DEngine:
         if tape is None:
             return out
 
+        g1, cut = self._bslice(geo, tape.grad_batch)
+        bx, bst, bh2, blsf, bff1 = cut(x), cut(st), cut(h2), cut(lsf), cut(ff1)
+        bsaved = [(cut(hin), cut(ls), cut(qkv), aname, ap) for (hin, ls, qkv, aname, ap) in saved]
+        fr1, hw1, T1 = g1.frames, g1.hw, g1.T
+
         def bwd():
             dout = tape.take(out)
-            has_seed = seeds is not None and any(s[3] in seeds for s in saved)
+            has_seed = seeds is not None and any(s[3] in seeds for s in bsaved)
             if dout is None and not has_seed:
                 return
             dh = None
             if dout is not None:
                 dh3 = ops.gemm(dout, w.lin_t(p + "proj_out.weight"))
                 dg = ops.gemm(dh3, w.lin_t(b + "ff.net.2.weight"))
-                dff1 = ops.geglu_bwd(dg, ff1)
+                dff1 = ops.geglu_bwd(dg, bff1)
                 dn = ops.gemm(dff1, w.lin_t(b + "ff.net.0.proj.weight"))
-                dh = ops.layernorm_bwd(dn, h2, lsf, w.vec(b + "ff_norm.weight"), add=dh3)
+                dh = ops.layernorm_bwd(dn, bh2, blsf, w.vec(b + "ff_norm.weight"), add=dh3)
             for a in reversed(range(n_attn)):
-                hin, ls, qkv, aname, ap = saved[a]
+                hin, ls, qkv, aname, ap = bsaved[a]
                 seed = seeds.get(aname) if seeds is not None else None
                 if dh is None and seed is None:
                     continue
                 da = ops.gemm(dh, w.lin_t(ap + "to_out.0.weight")) if dh is not None else None
-                dqkv = ops.empty((T, 3 * C), x)
+                dqkv = ops.empty((T1, 3 * C), x)
                 ops.tattn_bwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], da, dqkv[:, :C], dqkv[:, C:2 * C],
-                              dqkv[:, 2 * C:], geo.B, geo.F, hw, heads, d,
+                              dqkv[:, 2 * C:], g1.B, g1.F, hw1, heads, d,
                               ref_idx=seed[0] if seed else None, ref_val=seed[1] if seed else None,
                               seed_coef=seed[2] if seed else 0.0)
                 dn = ops.gemm(dqkv, w.cat_lin_t([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]))
                 dh = ops.layernorm_bwd(dn, hin, ls, w.vec(b + "norms.%d.weight" % a), add=dh)
             dhn = ops.gemm(dh, w.lin_t(p + "proj_in.weight"))
             if dout is not None:
-                dx = ops.gn_bwd(x, None, dhn, st, gN, bN, False, fr, hw, out=dout, accumulate=True)
+                dx = ops.gn_bwd(bx, None, dhn, bst, gN, bN, False, fr1, hw1, out=dout, accumulate=True)
             else:
-                dx = ops.gn_bwd(x, None, dhn, st, gN, bN, False, fr, hw)
+                dx = ops.gn_bwd(bx, None, dhn, bst, gN, bN, False, fr1, hw1)
             tape.give(x, dx)
         tape.add(bwd)
         return out
@@ -415,12 +455,14 @@ class UNet3DEngine:
         out = ops.gemm(x, w.conv(p + "weight"), bias=w.vec(p + "bias").unsqueeze(0), mode=CONV_S2,
                        geom=(geo.H, geo.W, g2.H, g2.W), m_out=g2.T)
         if tape is not None:
+            gb, _ = self._bslice(geo, tape.grad_batch)
+
             def bwd():
                 dout = tape.take(out)
                 if dout is None:
                     return
                 dx = ops.gemm(dout, w.conv_dgrad(p + "weight", stride=2), mode=TCONV_S2,
-                              geom=(g2.H, g2.W, geo.H, geo.W), m_out=geo.T)
+                              geom=(g2.H, g2.W, geo.H, geo.W), m_out=gb.T)
                 tape.give(x, dx)
             tape.add(bwd)
         return out, g2
@@ -431,12 +473,15 @@ class UNet3DEngine:
         out = ops.gemm(x, w.conv(p + "weight"), bias=w.vec(p + "bias").unsqueeze(0), mode=CONV_UP,
                        geom=(geo.H, geo.W, g2.H, g2.W), m_out=g2.T)
         if tape is not None:
+            gb, _ = self._bslice(geo, tape.grad_batch)
+            gb2 = gb.up()
+
             def bwd():
                 dout = tape.take(out)
                 if dout is None:
                     return
-                du = ops.gemm(dout, w.conv_dgrad(p + "weight"), mode=CONV_S1, geom=(g2.H, g2.W, g2.H, g2.W), m_out=g2.T)
-                tape.give(x, ops.sumpool2(du, geo.frames, geo.H, geo.W))
+                du = ops.gemm(dout, w.conv_dgrad(p + "weight"), mode=CONV_S1, geom=(g2.H, g2.W, g2.H, g2.W), m_out=gb2.T)
+                tape.give(x, ops.sumpool2(du, gb.frames, gb.H, gb.W))
             tape.add(bwd)
         return out, g2
 
@@ -467,9 +512,10 @@ class UNet3DEngine:
                 dout = tape.take(x0)
                 if dout is None:
                     return
+                nb = 1 if tape.grad_batch is not None else B
                 dxin = ops.gemm(dout, w.conv_dgrad("conv_in.weight", pad_cin=CIN_PAD), mode=CONV_S1,
-                                geom=(H, W, H, W), m_out=geo.T)
-                tape.latent_grad = ops.cl_to_latent(dxin, B, CL, F, H, W, scale=1.0 / self.grad_scale, f32=True)
+                                geom=(H, W, H, W), m_out=nb * F * H * W)
+                tape.latent_grad = ops.cl_to_latent(dxin, nb, CL, F, H, W, scale=1.0 / self.grad_scale, f32=True)
             tape.add(bwd_in)
         skips = [(x, geo)]
         for i in range(4):
@@ -551,17 +597,27 @@ class UNet3DEngine:
         return out
 
     def guided_eps_and_grad(self, latents, t, text_cond, rep_dev, weight, want_loss=False, down_residuals=None,
-                            mid_residual=None):
+                            mid_residual=None, text_uncond=None):
         """eps_c forward with the in-graph half taped + backward of  weight * sum_m mse_m  w.r.t. the latent
-        (motionclone_functions.py:221-236).  Returns (eps_c tokens, grad fp32 [1,4,F,H,W], loss or None)."""
-        tape = Tape()
+        (motionclone_functions.py:221-236).  With `text_uncond` the un-guided eps_u of :216-219 is produced by the same
+        launch sequence: one B = 2 forward over [uncond | cond] whose tape differentiates batch element 1 only
+        (residuals, if any, are then the B = 2 SparseCtrl outputs).
+        Returns (eps_c tokens, grad fp32 [1,4,F,H,W], loss or None[, eps_u tokens])."""
+        batched = text_uncond is not None
+        tape = Tape(grad_batch=1 if batched else None)
         seeds = {}
         for name, (idx, val) in rep_dev.items():
             numel = idx.numel()
             seeds[name] = (idx, val, self.grad_scale * float(weight) * 2.0 / numel)
         record = {}
-        eps_c = self.forward(latents, t, text_cond, tape=tape, record=record, seeds=seeds,
-                             down_residuals=down_residuals, mid_residual=mid_residual)
+        if batched:
+            eps2 = self.forward(latents.expand(2, -1, -1, -1, -1), t, torch.cat([text_uncond, text_cond], 0), tape=tape,
+                                record=record, seeds=seeds, down_residuals=down_residuals, mid_residual=mid_residual)
+            T1 = eps2.shape[0] // 2
+            eps_u, eps_c = eps2[:T1], eps2[T1:]
+        else:
+            eps_c = self.forward(latents, t, text_cond, tape=tape, record=record, seeds=seeds,
+                                 down_residuals=down_residuals, mid_residual=mid_residual)
         loss = None
         if want_loss:
             total = None
@@ -575,8 +631,9 @@ class UNet3DEngine:
         tape.run()
         grad = tape.latent_grad
         assert grad is not None, "guidance gradient did not reach the latent"
+        if batched:
+            return eps_c, grad, loss, eps_u
         return eps_c, grad, loss
-
 
 
 class ControlNetEngine(UNet3DEngine):

@@ -30,8 +30,11 @@ def uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale, num_tr
 class MotionCloneSampler:
     def __init__(self, engine, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                  num_inference_steps=30, guidance_steps=18, guidance_scale=0.4, score_guidance_scale=1.0,
-                 controlnet=None):
+                 controlnet=None, batch_guided=True):
         self.engine = engine
+        # True: guided steps run eps_u / eps_c as one B = 2 forward (same per-sample arithmetic as the reference's
+        # two B = 1 calls, fewer and larger launches); False: two separate forwards exactly as the reference issues them
+        self.batch_guided = batch_guided
         self.controlnet = controlnet     # ControlNetEngine or None (image-to-video, SparseCtrl)
         self.cfg_scale = float(cfg_scale)
         self.weight = float(motion_guidance_weight)
@@ -84,14 +87,20 @@ class MotionCloneSampler:
             shape2 = (2,) + tuple(latents.shape[1:])
             down, mid = self.controlnet.forward(shape2, t, text, ctrl["cond"], ctrl["mask"], ctrl.get("scale", 1.0))
         if i < self.G:
-            du = mu = dc = mc = None
-            if down is not None:
-                du, mu = split_residuals(down, mid, 0, 2)
-                dc, mc = split_residuals(down, mid, 1, 2)
-            eps_u = eng.forward(latents, t, text[0:1], down_residuals=du, mid_residual=mu)
             w = self.weight * self.guidance_factor(i)
-            eps_c, grad, loss = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w, want_loss=aux is not None,
-                                                        down_residuals=dc, mid_residual=mc)
+            if self.batch_guided:
+                # eps_u and eps_c from ONE B = 2 forward; only the conditional half is differentiated
+                eps_c, grad, loss, eps_u = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w,
+                                                                   want_loss=aux is not None, down_residuals=down,
+                                                                   mid_residual=mid, text_uncond=text[0:1])
+            else:
+                du = mu = dc = mc = None
+                if down is not None:
+                    du, mu = split_residuals(down, mid, 0, 2)
+                    dc, mc = split_residuals(down, mid, 1, 2)
+                eps_u = eng.forward(latents, t, text[0:1], down_residuals=du, mid_residual=mu)
+                eps_c, grad, loss = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w, want_loss=aux is not None,
+                                                            down_residuals=dc, mid_residual=mc)
             if aux is not None:
                 aux.update(eps_u=eps_u, eps_c=eps_c, grad=grad, loss=loss)
             coef = self.score_gs * (1.0 - a_t) ** 0.5

@@ -79,7 +79,8 @@ def test_extraction_matches_oracle(backend, tiny):
             assert mism.float().mean() < 0.02
 
 
-def test_guided_and_plain_step_match_oracle(backend, tiny):
+@pytest.mark.parametrize("batch_guided", [True, False], ids=["batchedB2", "twoB1"])
+def test_guided_and_plain_step_match_oracle(backend, tiny, batch_guided):
     dev = backend
     cfg, sd = tiny
     lat, text, vid, noise = make_inputs(cfg)
@@ -89,7 +90,8 @@ def test_guided_and_plain_step_match_oracle(backend, tiny):
     rep = G.extract_representation(sd, cfg, vid, noise, text16[[0]].float())
     ts = G.uneven_timesteps(N, Gs, gscale)
     eng = UNet3DEngine(sd, cfg, dev)
-    smp = MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gscale, **HP)
+    smp = MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gscale,
+                             batch_guided=batch_guided, **HP)
     assert smp.timesteps.tolist() == ts.tolist()
     rep_dev = eng.prepare_representation(rep)
 
