@@ -112,3 +112,16 @@ def test_guided_and_plain_step_match_oracle(backend, tiny, batch_guided):
     last = smp.step(p, N - 1, text16.to(dev), rep_dev)
     ref_last, _ = G.plain_step_full(sd, cfg, p.float().cpu(), N - 1, ts, text16.float(), HP["cfg_scale"])
     assert rel_err(last, ref_last) < 2e-2
+
+
+def test_forward_more_than_16_frames(backend, tiny):
+    """F = 20 -> two 16-wide tiles per side in the temporal-attention kernels (the config-5 code path, F = 32)"""
+    dev = backend
+    cfg, sd = tiny
+    lat = torch.randn(1, 4, 20, 8, 8, generator=torch.Generator().manual_seed(5)).half()
+    text = torch.randn(1, 7, cfg["cross_attention_dim"], generator=torch.Generator().manual_seed(7)).half()
+    eng = UNet3DEngine(sd, cfg, dev)
+    eps = eng.forward(lat.to(dev), 301, text.to(dev))
+    with torch.no_grad():
+        ref = U.unet_forward(sd, cfg, lat.float(), 301, text.float())
+    assert rel_err(ops.cl_to_latent(eps, 1, 4, 20, 8, 8).float().cpu(), ref) < 2e-2

@@ -1,0 +1,96 @@
+"""Full-size checks (BASELINE config 2: SD1.5 + AnimateDiff-v3 architecture, 16 f x 512 x 512 latents) through
+size-independent properties of the path - the oracle cannot run this size in seconds, the properties can:
+
+  * determinism: no atomics anywhere on the path -> bit-identical reruns;
+  * batching invariance: one B=2 forward == two B=1 forwards per sample (what the batched guided step relies on);
+  * self-consistency of the guidance: with the motion representation extracted from the SAME noisy latents, timestep
+    and text, gather(P, idx) == ref exactly, so the loss is 0 and the guidance gradient vanishes;
+  * linearity: the guidance gradient is linear in motion_guidance_weight (motionclone_functions.py:226);
+  * DDIM algebra: with score = 0 the guided update equals the plain update.
+"""
+import pytest
+import torch
+
+from motionclone_amd import ops, spec
+from motionclone_amd.engine import UNet3DEngine, default_config
+from motionclone_amd.sampler import MotionCloneSampler
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def full():
+    from motionclone_amd import lib
+    lib._lib = None
+    lib._is_emulated = False
+    lib.load()
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    sd, _ = spec.synthetic_state_dict(cfg, seed=1234, device=dev)
+    eng = UNet3DEngine(sd, cfg, dev)
+    g = torch.Generator(device=dev).manual_seed(2025)
+    lat = torch.randn((1, 4, 16, 64, 64), generator=g, device=dev, dtype=torch.float16)
+    text = torch.randn((2, 77, 768), generator=torch.Generator(device=dev).manual_seed(7), device=dev).half()
+    vid = (0.18215 * torch.randn((1, 4, 16, 64, 64), generator=torch.Generator(device=dev).manual_seed(11), device=dev)).half()
+    noise = torch.randn((1, 4, 16, 64, 64), generator=torch.Generator(device=dev).manual_seed(3), device=dev, dtype=torch.float16)
+    smp = MotionCloneSampler(eng, num_inference_steps=30, guidance_steps=18, guidance_scale=0.4)
+    return eng, smp, lat, text, vid, noise
+
+
+def rel(a, b):
+    return ((a.float() - b.float()).norm() / b.float().norm().clamp_min(1e-20)).item()
+
+
+def test_forward_is_deterministic_and_batch_invariant(full):
+    eng, smp, lat, text, _, _ = full
+    t = int(smp.timesteps[0])
+    e2a = eng.forward(lat.expand(2, -1, -1, -1, -1), t, text)
+    e2b = eng.forward(lat.expand(2, -1, -1, -1, -1), t, text)
+    assert torch.equal(e2a, e2b), "rerun differs bitwise"
+    assert torch.isfinite(e2a.float()).all()
+    T1 = e2a.shape[0] // 2
+    eu = eng.forward(lat, t, text[0:1])
+    ec = eng.forward(lat, t, text[1:2])
+    # the two batch sizes pick different GEMM tile geometries -> different fp32 summation order, nothing else
+    assert rel(e2a[:T1], eu) < 5e-3 and rel(e2a[T1:], ec) < 5e-3
+    assert rel(eu, ec) > 1e-2, "text conditioning has no effect?"
+
+
+def test_own_representation_gives_zero_loss_and_gradient(full):
+    eng, smp, lat, text, vid, noise = full
+    t = 400
+    noisy = smp.add_noise(t, vid, noise)
+    rep = eng.extract_representation(noisy, t, text[0:1])
+    assert len(rep) == 6
+    for v, i in rep.values():
+        assert v.shape == (256, 8, 16, 1) and i.dtype == torch.uint8 and int(i.max()) < 16
+        assert float(v.min()) >= 1.0 / 16 - 1e-3 and float(v.max()) <= 1.0   # a maximum of 16 probabilities
+    rep_dev = eng.prepare_representation(rep)
+    eps, grad, loss = eng.guided_eps_and_grad(noisy, t, text[0:1], rep_dev, 2000.0, want_loss=True)
+    # reference values are stored in fp16 (the reference's .pt format), so |P - ref| <= fp16 rounding of P
+    assert float(loss) < 2000.0 * 6 * (2.0 ** -11) ** 2
+    other = eng.guided_eps_and_grad(smp.add_noise(t, vid.flip(2), noise), t, text[0:1], rep_dev, 2000.0)[1]
+    assert grad.abs().max() < 1e-2 * other.abs().max(), "gradient on the video's own representation should vanish"
+
+
+def test_guidance_gradient_is_linear_in_weight_and_step_is_consistent(full):
+    eng, smp, lat, text, vid, noise = full
+    rep_dev = eng.prepare_representation(eng.extract_representation(smp.add_noise(400, vid, noise), 400, text[0:1]))
+    t = int(smp.timesteps[0])
+    _, g1, l1, eu = eng.guided_eps_and_grad(lat, t, text[1:2], rep_dev, 1000.0, want_loss=True, text_uncond=text[0:1])
+    ec, g2, l2, _ = eng.guided_eps_and_grad(lat, t, text[1:2], rep_dev, 2000.0, want_loss=True, text_uncond=text[0:1])
+    assert torch.isfinite(g2).all() and g2.abs().max() > 0
+    assert abs(float(l2) - 2 * float(l1)) < 1e-3 * abs(float(l2))
+    assert rel(g2, 2 * g1) < 2e-2      # fp16 gradient activations: linear up to rounding
+    # batched (B=2, sliced tape) and separate (B=1) guided paths agree
+    ec1, g3, _ = eng.guided_eps_and_grad(lat, t, text[1:2], rep_dev, 2000.0)
+    assert rel(g2, g3) < 3e-2 and rel(ec, ec1) < 5e-3
+    # DDIM algebra: zero score == plain update; the score only enters the direction term, linearly
+    a_t, a_prev = float(smp.acp[t]), float(smp.acp[int(smp.timesteps[1])])
+    zero = torch.zeros_like(g2)
+    x_plain = ops.cfg_ddim_step(ec, eu, lat, None, 7.5, a_t, a_prev, 0.0)
+    x_zero = ops.cfg_ddim_step(ec, eu, lat, zero, 7.5, a_t, a_prev, (1 - a_t) ** 0.5)
+    assert torch.equal(x_plain, x_zero)
+    x_g = ops.cfg_ddim_step(ec, eu, lat, g2, 7.5, a_t, a_prev, (1 - a_t) ** 0.5)
+    want = x_plain.float() - (1 - a_prev) ** 0.5 * (1 - a_t) ** 0.5 * g2
+    assert rel(x_g, want) < 2e-3
