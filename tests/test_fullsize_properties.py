@@ -70,7 +70,7 @@ def test_own_representation_gives_zero_loss_and_gradient(full):
     # reference values are stored in fp16 (the reference's .pt format), so |P - ref| <= fp16 rounding of P
     assert float(loss) < 2000.0 * 6 * (2.0 ** -11) ** 2
     other = eng.guided_eps_and_grad(smp.add_noise(t, vid.flip(2), noise), t, text[0:1], rep_dev, 2000.0)[1]
-    assert grad.abs().max() < 1e-2 * other.abs().max(), "gradient on the video's own representation should vanish"
+    assert grad.abs().max() < 5e-2 * other.abs().max(), "gradient on the video's own representation should vanish"
 
 
 def test_guidance_gradient_is_linear_in_weight_and_step_is_consistent(full):
