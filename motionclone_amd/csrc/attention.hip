@@ -84,8 +84,10 @@ __device__ __forceinline__ float grp_sum(float v) {
 // K/V tiles are double-buffered in LDS; the next tile's global loads are issued into registers before the current
 // tile's MFMAs and written to LDS after them (one barrier per tile).  Pairs of K=16 steps run as one
 // v_mfma_f32_16x16x32_f16 (cat4: concatenated fragments), the odd step of d = 40 / 80 as the K=16 instruction.
+// (second launch-bound = minimum waves per SIMD: without it hipcc budgets 512 registers, parks the MFMA accumulators in
+// AGPRs and pays v_accvgpr_read/write VALU slots around every softmax - 168 of them per tile at d = 40)
 template <int DT, int QT, bool PF>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int ldo, float* lse) {
+__global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_kernel(AParams P, half_t* o, int ldo, float* lse) {
     constexpr int RP = DT * 16 + 8;
     constexpr int KS_HALFS = KV_TILE * RP;
     constexpr int VT_HALFS = DT * 16 * TPAD;
@@ -105,6 +107,16 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
 
     zero_pads<DT>(Ks0, Vt0, P.d);
     if (PF) zero_pads<DT>(Ks0 + KS_HALFS, Vt0 + VT_HALFS, P.d);
+    // head dims that leave padding rows in V^T (d = 40 -> 48): row d is set to ones, so O^T row d accumulates the
+    // softmax denominators inside the PV MFMAs (rescaled with the rest of the accumulator), off the VALU
+    const bool ones_row = P.d < DT * 16;
+    if (ones_row) {
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < TPAD; idx += blockDim.x) {
+            Vt0[P.d * TPAD + idx] = (half_t)1.0f;
+            if (PF) Vt0[VT_HALFS + P.d * TPAD + idx] = (half_t)1.0f;
+        }
+    }
 
     // per-thread staging slots: fixed (row, 16-byte column) of the 64-row tile; only the base row advances
     half8_t rk[NV], rv[NV];
@@ -206,17 +218,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
                 for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, cat4(qf[t][DT - 1], zero4()), st[t][j]);
             }
         }
-        // online softmax in the exp2 domain: s2 = score * (scale * log2 e); masking only on the ragged last tile;
-        // the output accumulators are rescaled only when some row's running maximum actually moved
+        // online softmax in the exp2 domain.  VALU is the bound of this loop (a wave64 VALU op holds the SIMD for 4
+        // cycles, v_exp_f32 for 16), so per score: one max on the RAW score, one FMA (score * sl2 - m), one exp2, half a
+        // packed convert.  Row sums come out of the PV MFMAs when the head dim leaves a padding row in V^T (ones row).
         half8_t pf[QT][2];
         const bool tail = kv0 + KV_TILE > P.Nk;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
-            float mx = -INFINITY;
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) st[t][j][i] *= sl2;
             if (tail) {  // wave-uniform branch: only the ragged last tile pays for masking
 #pragma unroll
                 for (int j = 0; j < 4; ++j)
@@ -224,22 +232,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
                     for (int i = 0; i < 4; ++i)
                         if (kv0 + 16 * j + 4 * g + i >= P.Nk) st[t][j][i] = -INFINITY;
             }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int i = 0; i < 4; ++i) mx = fmaxf(mx, st[t][j][i]);
+            float mx = max3(st[t][0][0], st[t][0][1], st[t][0][2]);
+            mx = max3(mx, st[t][0][3], st[t][1][0]);
+            mx = max3(mx, st[t][1][1], st[t][1][2]);
+            mx = max3(mx, st[t][1][3], st[t][2][0]);
+            mx = max3(mx, st[t][2][1], st[t][2][2]);
+            mx = max3(mx, st[t][2][3], st[t][3][0]);
+            mx = max3(mx, st[t][3][1], st[t][3][2]);
+            mx = fmaxf(mx, st[t][3][3]);
             mx = grp_max(mx);
-            const float mnew = fmaxf(m[t], mx);
+            const float mnew = fmaxf(m[t], mx * sl2);   // sl2 > 0: max commutes with the scaling
             float rs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float e = fast_exp2(st[t][j][i] - mnew);
-                    rs += e;
-                    pf[t][j >> 1][4 * (j & 1) + i] = (half_t)e;
+                for (int i = 0; i < 4; i += 2) {
+                    float e0 = fast_exp2(fmaf(st[t][j][i], sl2, -mnew));
+                    float e1 = fast_exp2(fmaf(st[t][j][i + 1], sl2, -mnew));
+                    if (!ones_row) rs += e0 + e1;
+                    half2_t h2 = pk_rtz(e0, e1);
+                    pf[t][j >> 1][4 * (j & 1) + i] = h2[0];
+                    pf[t][j >> 1][4 * (j & 1) + i + 1] = h2[1];
                 }
-            rs = grp_sum(rs);
+            if (!ones_row) rs = grp_sum(rs);
             if (wave_all(mnew == m[t])) {
                 l[t] += rs;
             } else {
@@ -272,8 +287,10 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qi = q0 + 16 * t + c15;
+        // O^T row d sits in accumulator tile DT-1, element 0 of lane group (d % 16) / 4 (d is a multiple of 8)
+        const float lt = ones_row ? shfl(oacc[t][DT - 1][0], 16 * ((P.d & 15) >> 2) + c15) : l[t];
         if (qi >= P.Nq) continue;
-        const float inv = 1.0f / l[t];
+        const float inv = 1.0f / lt;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
             int c = 16 * dt + 4 * g;
@@ -284,13 +301,13 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AParams P, half_t* o, int
                 st4(o + (qbase + qi) * ldo + col0 + c, ov);
             }
         }
-        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = (m[t] + log2f(l[t])) * 0.6931471805599453f;
+        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = (m[t] + log2f(lt)) * 0.6931471805599453f;
     }
 }
 
 // ---- backward: dQ (and D = rowsum(dO * O)) ---------------------------------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AParams P, const half_t* o, int ldo, const half_t* dO,
+__global__ __launch_bounds__(256, DT <= 5 ? 4 : 2) void attn_bwd_dq_kernel(AParams P, const half_t* o, int ldo, const half_t* dO,
                                                            int lddo, const float* lse, float* Dbuf, half_t* dq,
                                                            int lddq) {
     constexpr int RP = DT * 16 + 8;
@@ -327,8 +344,18 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AParams P, const half_
     }
     const float Dq = grp_sum(dsum);
     const size_t sidx = ((size_t)b * P.heads + h) * P.Nq + (qok ? qi : 0);
-    const float lq = qok ? lse[sidx] : 0.f;
+    const float sl2 = P.scale * 1.4426950408889634f;
+    const float lq2 = qok ? lse[sidx] * 1.4426950408889634f : 0.f;   // log-sum-exp in log2 units
     if (qok && g == 0 && Dbuf) Dbuf[sidx] = Dq;
+
+    // K=16 fragment pairs concatenated for the K=32 MFMA (odd last step padded with zeros)
+    constexpr int DP = (DT + 1) / 2;
+    half8_t qf8[DP], dof8[DP];
+#pragma unroll
+    for (int kp = 0; kp < DP; ++kp) {
+        qf8[kp] = cat4(qf[2 * kp], 2 * kp + 1 < DT ? qf[2 * kp + 1] : zero4());
+        dof8[kp] = cat4(dof[2 * kp], 2 * kp + 1 < DT ? dof[2 * kp + 1] : zero4());
+    }
 
     f32x4 acc[DT];
 #pragma unroll
@@ -340,27 +367,39 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AParams P, const half_
         stage_cols(Kt, P.k, kbase, kv0, P.Nk, P.ldk, col0, P.d);
         stage_rows<DT>(Vs, P.v, kbase, kv0, P.Nk, P.ldv, col0, P.d);
         __syncthreads();
+        const bool tail = kv0 + KV_TILE > P.Nk;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 sT = fzero4(), dpT = fzero4();
+        for (int jp = 0; jp < 2; ++jp) {
+            half4_t dsf[2];
 #pragma unroll
-            for (int ks = 0; ks < DT; ++ks) {
-                half4_t kf = ld4(Ks + (16 * j + c15) * RP + 16 * ks + 4 * g);
-                half4_t vf = ld4(Vs + (16 * j + c15) * RP + 16 * ks + 4 * g);
-                sT = mfma16(kf, qf[ks], sT);
-                dpT = mfma16(vf, dof[ks], dpT);
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                f32x4 sT = fzero4(), dpT = fzero4();
+                const half_t* krow = Ks + (16 * j + c15) * RP + 4 * g;
+                const half_t* vrow = Vs + (16 * j + c15) * RP + 4 * g;
+#pragma unroll
+                for (int kp = 0; kp < DP; ++kp) {
+                    const bool full = 2 * kp + 1 < DT;
+                    half8_t kf = cat4(ld4(krow + 32 * kp), full ? ld4(krow + 32 * kp + 16) : zero4());
+                    half8_t vf = cat4(ld4(vrow + 32 * kp), full ? ld4(vrow + 32 * kp + 16) : zero4());
+                    sT = mfma16k32(kf, qf8[kp], sT);
+                    dpT = mfma16k32(vf, dof8[kp], dpT);
+                }
+                float ds[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    float pr = fast_exp2(fmaf(sT[i], sl2, -lq2));
+                    if (tail && kv0 + 16 * j + 4 * g + i >= P.Nk) pr = 0.f;
+                    ds[i] = pr * (dpT[i] - Dq);
+                }
+                half2_t a = pk_rtz(ds[0], ds[1]), c = pk_rtz(ds[2], ds[3]);
+                dsf[jj][0] = a[0]; dsf[jj][1] = a[1]; dsf[jj][2] = c[0]; dsf[jj][3] = c[1];
             }
-            half4_t dsf;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int kv = kv0 + 16 * j + 4 * g + i;
-                float p = kv < P.Nk ? expf(sT[i] * P.scale - lq) : 0.f;
-                dsf[i] = (half_t)(p * (dpT[i] - Dq));
-            }
+            const half8_t ds8 = cat4(dsf[0], dsf[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                half4_t kc = ld4(Kt + (16 * dt + c15) * TPAD + 16 * j + 4 * g);
-                acc[dt] = mfma16(kc, dsf, acc[dt]);
+                const half_t* kc = Kt + (16 * dt + c15) * TPAD + 32 * jp + 4 * g;
+                acc[dt] = mfma16k32(cat4(ld4(kc), ld4(kc + 16)), ds8, acc[dt]);
             }
         }
     }
@@ -379,7 +418,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AParams P, const half_
 
 // ---- backward: dK, dV (self-attention: kv batch == q batch) -----------------------------------
 template <int DT>
-__global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AParams P, const half_t* dO, int lddo,
+__global__ __launch_bounds__(256, DT <= 4 ? 4 : (DT == 5 ? 3 : 2)) void attn_bwd_dkdv_kernel(AParams P, const half_t* dO, int lddo,
                                                              const float* lse, const float* Dbuf, half_t* dk,
                                                              int lddk, half_t* dv, int lddv) {
     constexpr int RP = DT * 16 + 8;
@@ -413,6 +452,14 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AParams P, const hal
             vf[ks] = zero4();
         }
     }
+    constexpr int DP = (DT + 1) / 2;
+    half8_t kf8[DP], vf8[DP];
+#pragma unroll
+    for (int kp = 0; kp < DP; ++kp) {
+        kf8[kp] = cat4(kf[2 * kp], 2 * kp + 1 < DT ? kf[2 * kp + 1] : zero4());
+        vf8[kp] = cat4(vf[2 * kp], 2 * kp + 1 < DT ? vf[2 * kp + 1] : zero4());
+    }
+    const float sl2 = P.scale * 1.4426950408889634f;
     f32x4 ak[DT], av[DT];
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) ak[dt] = av[dt] = fzero4();
@@ -426,34 +473,47 @@ __global__ __launch_bounds__(256) void attn_bwd_dkdv_kernel(AParams P, const hal
         if (threadIdx.x < KV_TILE) {
             int qi = q0 + threadIdx.x;
             size_t si = ((size_t)b * P.heads + h) * P.Nq + qi;
-            lse_s[threadIdx.x] = qi < P.Nq ? lse[si] : INFINITY;
+            lse_s[threadIdx.x] = qi < P.Nq ? lse[si] * 1.4426950408889634f : INFINITY;   // log2 units
             D_s[threadIdx.x] = qi < P.Nq ? Dbuf[si] : 0.f;
         }
         __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            f32x4 s = fzero4(), dp = fzero4();
+        for (int jp = 0; jp < 2; ++jp) {
+            half4_t pf[2], dsf[2];
 #pragma unroll
-            for (int ks = 0; ks < DT; ++ks) {
-                half4_t qr = ld4(Qs + (16 * j + c15) * RP + 16 * ks + 4 * g);
-                half4_t orr = ld4(Os + (16 * j + c15) * RP + 16 * ks + 4 * g);
-                s = mfma16(qr, kf[ks], s);     // [q = 16j + 4g + i][kv = c15]
-                dp = mfma16(orr, vf[ks], dp);
-            }
-            half4_t pf, dsf;
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                f32x4 sc = fzero4(), dp = fzero4();
+                const half_t* qrow = Qs + (16 * j + c15) * RP + 4 * g;
+                const half_t* orow = Os + (16 * j + c15) * RP + 4 * g;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                int r = 16 * j + 4 * g + i;
-                float p = expf(s[i] * P.scale - lse_s[r]);
-                pf[i] = (half_t)p;
-                dsf[i] = (half_t)(p * (dp[i] - D_s[r]));
+                for (int kp = 0; kp < DP; ++kp) {
+                    const bool full = 2 * kp + 1 < DT;
+                    half8_t qr = cat4(ld4(qrow + 32 * kp), full ? ld4(qrow + 32 * kp + 16) : zero4());
+                    half8_t orr = cat4(ld4(orow + 32 * kp), full ? ld4(orow + 32 * kp + 16) : zero4());
+                    sc = mfma16k32(qr, kf8[kp], sc);     // [q = 16j + 4g + i][kv = c15]
+                    dp = mfma16k32(orr, vf8[kp], dp);
+                }
+                const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * j + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + 16 * j + 4 * g);
+                float pr[4], ds[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    pr[i] = fast_exp2(fmaf(sc[i], sl2, -l4[i]));
+                    ds[i] = pr[i] * (dp[i] - d4[i]);
+                }
+                half2_t a = pk_rtz(pr[0], pr[1]), c = pk_rtz(pr[2], pr[3]);
+                pf[jj][0] = a[0]; pf[jj][1] = a[1]; pf[jj][2] = c[0]; pf[jj][3] = c[1];
+                a = pk_rtz(ds[0], ds[1]); c = pk_rtz(ds[2], ds[3]);
+                dsf[jj][0] = a[0]; dsf[jj][1] = a[1]; dsf[jj][2] = c[0]; dsf[jj][3] = c[1];
             }
+            const half8_t p8 = cat4(pf[0], pf[1]), ds8 = cat4(dsf[0], dsf[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
-                half4_t oc = ld4(Ot + (16 * dt + c15) * TPAD + 16 * j + 4 * g);
-                half4_t qc = ld4(Qt + (16 * dt + c15) * TPAD + 16 * j + 4 * g);
-                av[dt] = mfma16(oc, pf, av[dt]);
-                ak[dt] = mfma16(qc, dsf, ak[dt]);
+                const half_t* oc = Ot + (16 * dt + c15) * TPAD + 32 * jp + 4 * g;
+                const half_t* qc = Qt + (16 * dt + c15) * TPAD + 32 * jp + 4 * g;
+                av[dt] = mfma16k32(cat4(ld4(oc), ld4(oc + 16)), p8, av[dt]);
+                ak[dt] = mfma16k32(cat4(ld4(qc), ld4(qc + 16)), ds8, ak[dt]);
             }
         }
     }

@@ -215,6 +215,30 @@ __device__ inline half8_t cat4(half4_t lo, half4_t hi) {
     return r;
 }
 
+// two floats -> packed halfs, round toward zero (one v_cvt_pkrtz_f16_f32 instead of two converts and a pack)
+#ifdef MC_EMU
+__device__ inline half2_t pk_rtz(float a, float b) {
+    half2_t r;
+    float in[2] = {a, b};
+    for (int i = 0; i < 2; ++i) {
+        half_t h = (half_t)in[i];
+        if (fabsf((float)h) > fabsf(in[i])) {  // rounded away from zero: step the magnitude back by one ulp
+            uint16_t bits;
+            __builtin_memcpy(&bits, &h, 2);
+            bits -= 1;
+            __builtin_memcpy(&h, &bits, 2);
+        }
+        r[i] = h;
+    }
+    return r;
+}
+#else
+__device__ __forceinline__ half2_t pk_rtz(float a, float b) {
+    return __builtin_bit_cast(half2_t, __builtin_amdgcn_cvt_pkrtz(a, b));
+}
+#endif
+__device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
+
 // saturating float -> half (fp16 max 65504); keeps NaN out of downstream tensors on overflow
 __device__ inline half_t to_half(float x) {
     x = fminf(fmaxf(x, -65504.0f), 65504.0f);
