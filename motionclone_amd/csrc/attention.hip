@@ -45,16 +45,24 @@ __device__ __forceinline__ void stage_rows(half_t* dst, const half_t* src, size_
         *reinterpret_cast<half8_t*>(dst + r * RP + vcol * 8) = val;
     }
 }
-// same rows, stored transposed: dst[c][r] (row length TPAD)
+// same rows, stored transposed: dst[c][r] (row length TPAD).  Each thread takes the same 8 columns of two adjacent
+// rows and writes 8 packed b32 {row r, row r+1}: 32 lanes fill 32 consecutive dwords of one transposed row and the
+// wave's two column groups sit 32 banks apart - a conflict-free transpose (scalar b16 writes were ~5-way conflicted)
 __device__ __forceinline__ void stage_cols(half_t* dst, const half_t* src, size_t row_base, int r0, int nrows,
                                            int ld, int col0, int d) {
     const int vpr = d / 8;
-    for (int idx = threadIdx.x; idx < KV_TILE * vpr; idx += blockDim.x) {
-        int r = idx / vpr, vcol = idx - r * vpr;
-        half8_t val = zero8();
-        if (r0 + r < nrows) val = ld8(src + (row_base + r0 + r) * ld + col0 + vcol * 8);
+    for (int pidx = threadIdx.x; pidx < (KV_TILE / 2) * vpr; pidx += blockDim.x) {
+        const int vcol = pidx >> 5, r = 2 * (pidx & 31);
+        const half_t* p = src + (row_base + r0 + r) * ld + col0 + vcol * 8;
+        half8_t va = r0 + r < nrows ? ld8(p) : zero8();
+        half8_t vb = r0 + r + 1 < nrows ? ld8(p + ld) : zero8();
 #pragma unroll
-        for (int e = 0; e < 8; ++e) dst[(vcol * 8 + e) * TPAD + r] = val[e];
+        for (int e = 0; e < 8; ++e) {
+            half2_t pr;
+            pr[0] = va[e];
+            pr[1] = vb[e];
+            *reinterpret_cast<half2_t*>(dst + (vcol * 8 + e) * TPAD + r) = pr;
+        }
     }
 }
 // zero the padding columns [d, DT*16) of a row-major tile and padding rows of a transposed tile
@@ -118,42 +126,63 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
         }
     }
 
-    // per-thread staging slots: fixed (row, 16-byte column) of the 64-row tile; only the base row advances
-    half8_t rk[NV], rv[NV];
-    bool s_ok[NV];
-    int s_row[NV], s_lk[NV], s_lv[NV];
-    const half_t* s_pk[NV];
-    const half_t* s_pv[NV];
+    // per-thread staging slots; only the base row advances.  K: fixed (row, 16-byte column) of the 64-row tile, written
+    // row-major as one b128.  V: fixed (row PAIR, 16-byte column): the thread holds the same 8 columns of two adjacent
+    // kv rows and writes the transposed image as 8 packed b32 {V[r][c], V[r+1][c]} - 32 lanes cover 32 consecutive
+    // dwords of one V^T row and the two column groups of a wave land 32 banks apart, so the transpose costs no LDS
+    // bank conflicts (the former 16 ds_write_b16 per thread kept the LDS pipe ~75 % busy, over half of it conflicts)
+    constexpr int NVP = (KV_TILE / 2 * DT * 2 + 255) / 256;
+    half8_t rk[NV], rva[NVP], rvb[NVP];
+    bool s_ok[NV], v_ok[NVP];
+    int s_lk[NV], v_l[NVP];
+    uint32_t s_ok_off[NV], v_off[NVP];   // byte offsets into this batch's K / V rows (hardware range check: rows >= Nk -> 0)
+    const GBuf kbuf = make_gbuf(P.k + kbase * P.ldk, (uint32_t)P.Nk * P.ldk * 2);
+    const GBuf vbuf = make_gbuf(P.v + kbase * P.ldv, (uint32_t)P.Nk * P.ldv * 2);
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         int idx = threadIdx.x + 256 * i;
         int r = idx / vpr, vcol = idx - r * vpr;
         s_ok[i] = idx < KV_TILE * vpr;
-        s_row[i] = r;
         s_lk[i] = r * RP + vcol * 8;
-        s_lv[i] = vcol * 8 * TPAD + r;
-        s_pk[i] = P.k + (kbase + r) * P.ldk + col0 + vcol * 8;
-        s_pv[i] = P.v + (kbase + r) * P.ldv + col0 + vcol * 8;
+        s_ok_off[i] = (uint32_t)(r * P.ldk + col0 + vcol * 8) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < NVP; ++i) {
+        int pidx = threadIdx.x + 256 * i;
+        int vcol = pidx >> 5, rp = pidx & 31;
+        v_ok[i] = vcol < vpr;
+        v_l[i] = vcol * 8 * TPAD + 2 * rp;
+        v_off[i] = (uint32_t)(2 * rp * P.ldv + col0 + vcol * 8) * 2;
     }
     auto load_regs = [&](int kv0) {
+        const uint32_t ko = (uint32_t)kv0 * P.ldk * 2, vo = (uint32_t)kv0 * P.ldv * 2;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            bool ok = s_ok[i] && kv0 + s_row[i] < P.Nk;
-            rk[i] = ok ? ld8(s_pk[i] + (size_t)kv0 * P.ldk) : zero8();
-            rv[i] = ok ? ld8(s_pv[i] + (size_t)kv0 * P.ldv) : zero8();
-        }
+        for (int i = 0; i < NV; ++i)
+            if (s_ok[i]) rk[i] = gbuf_ld8(kbuf, s_ok_off[i] + ko);
+#pragma unroll
+        for (int i = 0; i < NVP; ++i)
+            if (v_ok[i]) {
+                rva[i] = gbuf_ld8(vbuf, v_off[i] + vo);
+                rvb[i] = gbuf_ld8(vbuf, v_off[i] + vo + (uint32_t)P.ldv * 2);
+            }
     };
     auto store_regs = [&](int buf) {
         half_t* Ks = Ks0 + buf * KS_HALFS;
         half_t* Vt = Vt0 + buf * VT_HALFS;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            if (s_ok[i]) {
-                *reinterpret_cast<half8_t*>(Ks + s_lk[i]) = rk[i];
+        for (int i = 0; i < NV; ++i)
+            if (s_ok[i]) *reinterpret_cast<half8_t*>(Ks + s_lk[i]) = rk[i];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) Vt[s_lv[i] + e * TPAD] = rv[i][e];
+        for (int i = 0; i < NVP; ++i)
+            if (v_ok[i]) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    half2_t pr;
+                    pr[0] = rva[i][e];
+                    pr[1] = rvb[i][e];
+                    *reinterpret_cast<half2_t*>(Vt + v_l[i] + e * TPAD) = pr;
+                }
             }
-        }
     };
 
     half4_t qf[QT][DT];
@@ -196,11 +225,7 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
         const half_t* Ks = Ks0 + buf * KS_HALFS;
         const half_t* Vt = Vt0 + buf * VT_HALFS;
 
-        f32x4 st[QT][4];
-#pragma unroll
-        for (int t = 0; t < QT; ++t)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) st[t][j] = fzero4();
+        f32x4 st[QT][4];   // first MFMA of each tile takes the inline-constant zero as C: no accumulator clearing
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const half_t* krow = Ks + (16 * j + c15) * RP + 4 * g;
@@ -208,14 +233,16 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
             for (int ks = 0; ks + 1 < DT; ks += 2) {
                 half8_t kf = cat4(ld4(krow + 16 * ks), ld4(krow + 16 * ks + 16));
 #pragma unroll
-                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, cat4(qf[t][ks], qf[t][ks + 1]), st[t][j]);
+                for (int t = 0; t < QT; ++t)
+                    st[t][j] = mfma16k32(kf, cat4(qf[t][ks], qf[t][ks + 1]), ks == 0 ? fzero4() : st[t][j]);
             }
             if (DT & 1) {
                 // odd step: same K=32 instruction with the upper k-slots zero.  (A dependent legacy 16x16x16 MFMA
                 // issued right behind 16x16x32 ones on the same accumulator returned wrong sums on gfx950.)
                 half8_t kf = cat4(ld4(krow + 16 * (DT - 1)), zero4());
 #pragma unroll
-                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, cat4(qf[t][DT - 1], zero4()), st[t][j]);
+                for (int t = 0; t < QT; ++t)
+                    st[t][j] = mfma16k32(kf, cat4(qf[t][DT - 1], zero4()), DT == 1 ? fzero4() : st[t][j]);
             }
         }
         // online softmax in the exp2 domain.  VALU is the bound of this loop (a wave64 VALU op holds the SIMD for 4

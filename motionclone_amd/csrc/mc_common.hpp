@@ -117,6 +117,15 @@ __device__ inline void glds16(GBuf b, uint32_t voff, char* lds_wave_base) {
     else
         memset(d, 0, 16);
 }
+// 16-byte buffer load into registers with the same hardware range check (out of range -> zeros, no VALU select)
+__device__ inline half8_t gbuf_ld8(GBuf b, uint32_t voff) {
+    half8_t r;
+    if ((uint64_t)voff + 16 <= b.bytes)
+        memcpy(&r, b.base + voff, 16);
+    else
+        memset(&r, 0, 16);
+    return r;
+}
 #else
 typedef __amdgpu_buffer_rsrc_t GBuf;
 __device__ __forceinline__ GBuf make_gbuf(const void* p, uint32_t bytes) {
@@ -125,6 +134,11 @@ __device__ __forceinline__ GBuf make_gbuf(const void* p, uint32_t bytes) {
 __device__ __forceinline__ void glds16(GBuf b, uint32_t voff, char* lds_wave_base) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(b, (__attribute__((address_space(3))) void*)lds_wave_base, 16,
                                              (int)voff, 0, 0, 0);
+}
+#endif
+#ifndef MC_EMU
+__device__ __forceinline__ half8_t gbuf_ld8(GBuf b, uint32_t voff) {
+    return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, 0, 0));
 }
 #endif
 // counted wait on this wave's outstanding vector-memory operations, and a bare workgroup barrier (no fence)
