@@ -333,11 +333,14 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
 }
 
 // ---- backward: dQ (and D = rowsum(dO * O)) ---------------------------------------------------
-template <int DT>
-__global__ __launch_bounds__(256, DT <= 5 ? 4 : 2) void attn_bwd_dq_kernel(AParams P, const half_t* o, int ldo, const half_t* dO,
-                                                           int lddo, const float* lse, float* Dbuf, half_t* dq,
-                                                           int lddq) {
+// QT query tiles (16 rows each) per wave: every K / V / K^T fragment read from LDS feeds QT MFMAs, and a block's
+// staged tile serves 64*QT query rows.
+template <int DT, int QT>
+__global__ __launch_bounds__(256, (QT == 1 && DT <= 5) ? 4 : 2) void attn_bwd_dq_kernel(
+    AParams P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse, float* Dbuf, half_t* dq,
+    int lddq) {
     constexpr int RP = DT * 16 + 8;
+    constexpr int DP = (DT + 1) / 2;
     MC_DYN_SMEM(smem);
     half_t* Ks = reinterpret_cast<half_t*>(smem);  // [64][RP]
     half_t* Vs = Ks + KV_TILE * RP;                // [64][RP]
@@ -347,46 +350,51 @@ __global__ __launch_bounds__(256, DT <= 5 ? 4 : 2) void attn_bwd_dq_kernel(APara
     const int h = blockIdx.y, b = blockIdx.z;
     const int col0 = h * P.d;
     const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)(b / P.kv_bdiv) * P.Nk;
-    const int qi = blockIdx.x * 64 + wave * 16 + c15;
-    const bool qok = qi < P.Nq;
+    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const float sl2 = P.scale * 1.4426950408889634f;
 
     zero_pads<DT>(Ks, Kt, P.d);
     zero_pads<DT>(Vs, nullptr, P.d);
 
-    half4_t qf[DT], dof[DT];
-    float dsum = 0.f;
-#pragma unroll
-    for (int ks = 0; ks < DT; ++ks) {
-        int c = 16 * ks + 4 * g;
-        if (qok && c < P.d) {
-            qf[ks] = ld4(P.q + (qbase + qi) * P.ldq + col0 + c);
-            dof[ks] = ld4(dO + (qbase + qi) * lddo + col0 + c);
-            half4_t ov = ld4(o + (qbase + qi) * ldo + col0 + c);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) dsum += (float)dof[ks][i] * (float)ov[i];
-        } else {
-            qf[ks] = zero4();
-            dof[ks] = zero4();
-        }
-    }
-    const float Dq = grp_sum(dsum);
-    const size_t sidx = ((size_t)b * P.heads + h) * P.Nq + (qok ? qi : 0);
-    const float sl2 = P.scale * 1.4426950408889634f;
-    const float lq2 = qok ? lse[sidx] * 1.4426950408889634f : 0.f;   // log-sum-exp in log2 units
-    if (qok && g == 0 && Dbuf) Dbuf[sidx] = Dq;
-
     // K=16 fragment pairs concatenated for the K=32 MFMA (odd last step padded with zeros)
-    constexpr int DP = (DT + 1) / 2;
-    half8_t qf8[DP], dof8[DP];
+    half8_t qf8[QT][DP], dof8[QT][DP];
+    float Dq[QT], lq2[QT];
 #pragma unroll
-    for (int kp = 0; kp < DP; ++kp) {
-        qf8[kp] = cat4(qf[2 * kp], 2 * kp + 1 < DT ? qf[2 * kp + 1] : zero4());
-        dof8[kp] = cat4(dof[2 * kp], 2 * kp + 1 < DT ? dof[2 * kp + 1] : zero4());
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + 16 * t + c15;
+        const bool qok = qi < P.Nq;
+        half4_t qf[2 * DP], dof[2 * DP];
+        float dsum = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2 * DP; ++ks) {
+            int c = 16 * ks + 4 * g;
+            if (qok && c < P.d) {
+                qf[ks] = ld4(P.q + (qbase + qi) * P.ldq + col0 + c);
+                dof[ks] = ld4(dO + (qbase + qi) * lddo + col0 + c);
+                half4_t ov = ld4(o + (qbase + qi) * ldo + col0 + c);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) dsum += (float)dof[ks][i] * (float)ov[i];
+            } else {
+                qf[ks] = zero4();
+                dof[ks] = zero4();
+            }
+        }
+#pragma unroll
+        for (int kp = 0; kp < DP; ++kp) {
+            qf8[t][kp] = cat4(qf[2 * kp], qf[2 * kp + 1]);
+            dof8[t][kp] = cat4(dof[2 * kp], dof[2 * kp + 1]);
+        }
+        Dq[t] = grp_sum(dsum);
+        const size_t sidx = ((size_t)b * P.heads + h) * P.Nq + (qok ? qi : 0);
+        lq2[t] = qok ? lse[sidx] * 1.4426950408889634f : 0.f;   // log-sum-exp in log2 units
+        if (qok && g == 0 && Dbuf) Dbuf[sidx] = Dq[t];
     }
 
-    f32x4 acc[DT];
+    f32x4 acc[QT][DT];
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) acc[dt] = fzero4();
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[t][dt] = fzero4();
 
     for (int kv0 = 0; kv0 < P.Nk; kv0 += KV_TILE) {
         __syncthreads();
@@ -397,11 +405,11 @@ __global__ __launch_bounds__(256, DT <= 5 ? 4 : 2) void attn_bwd_dq_kernel(APara
         const bool tail = kv0 + KV_TILE > P.Nk;
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
-            half4_t dsf[2];
+            half4_t dsf[QT][2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
-                f32x4 sT = fzero4(), dpT = fzero4();
+                f32x4 sT[QT], dpT[QT];
                 const half_t* krow = Ks + (16 * j + c15) * RP + 4 * g;
                 const half_t* vrow = Vs + (16 * j + c15) * RP + 4 * g;
 #pragma unroll
@@ -409,46 +417,59 @@ __global__ __launch_bounds__(256, DT <= 5 ? 4 : 2) void attn_bwd_dq_kernel(APara
                     const bool full = 2 * kp + 1 < DT;
                     half8_t kf = cat4(ld4(krow + 32 * kp), full ? ld4(krow + 32 * kp + 16) : zero4());
                     half8_t vf = cat4(ld4(vrow + 32 * kp), full ? ld4(vrow + 32 * kp + 16) : zero4());
-                    sT = mfma16k32(kf, qf8[kp], sT);
-                    dpT = mfma16k32(vf, dof8[kp], dpT);
-                }
-                float ds[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    float pr = fast_exp2(fmaf(sT[i], sl2, -lq2));
-                    if (tail && kv0 + 16 * j + 4 * g + i >= P.Nk) pr = 0.f;
-                    ds[i] = pr * (dpT[i] - Dq);
+                    for (int t = 0; t < QT; ++t) {
+                        sT[t] = mfma16k32(kf, qf8[t][kp], kp == 0 ? fzero4() : sT[t]);
+                        dpT[t] = mfma16k32(vf, dof8[t][kp], kp == 0 ? fzero4() : dpT[t]);
+                    }
                 }
-                half2_t a = pk_rtz(ds[0], ds[1]), c = pk_rtz(ds[2], ds[3]);
-                dsf[jj][0] = a[0]; dsf[jj][1] = a[1]; dsf[jj][2] = c[0]; dsf[jj][3] = c[1];
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    float ds[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        float pr = fast_exp2(fmaf(sT[t][i], sl2, -lq2[t]));
+                        if (tail && kv0 + 16 * j + 4 * g + i >= P.Nk) pr = 0.f;
+                        ds[i] = pr * (dpT[t][i] - Dq[t]);
+                    }
+                    half2_t a = pk_rtz(ds[0], ds[1]), c = pk_rtz(ds[2], ds[3]);
+                    dsf[t][jj][0] = a[0]; dsf[t][jj][1] = a[1]; dsf[t][jj][2] = c[0]; dsf[t][jj][3] = c[1];
+                }
             }
-            const half8_t ds8 = cat4(dsf[0], dsf[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const half_t* kc = Kt + (16 * dt + c15) * TPAD + 32 * jp + 4 * g;
-                acc[dt] = mfma16k32(cat4(ld4(kc), ld4(kc + 16)), ds8, acc[dt]);
+                const half8_t k8 = cat4(ld4(kc), ld4(kc + 16));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t][dt] = mfma16k32(k8, cat4(dsf[t][0], dsf[t][1]), acc[t][dt]);
             }
         }
     }
-    if (!qok) return;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        int c = 16 * dt + 4 * g;
-        if (c < P.d) {
-            half4_t ov;
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + 16 * t + c15;
+        if (qi >= P.Nq) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) ov[i] = to_half(acc[dt][i] * P.scale);
-            st4(dq + (qbase + qi) * lddq + col0 + c, ov);
+        for (int dt = 0; dt < DT; ++dt) {
+            int c = 16 * dt + 4 * g;
+            if (c < P.d) {
+                half4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = to_half(acc[t][dt][i] * P.scale);
+                st4(dq + (qbase + qi) * lddq + col0 + c, ov);
+            }
         }
     }
 }
 
 // ---- backward: dK, dV (self-attention: kv batch == q batch) -----------------------------------
-template <int DT>
-__global__ __launch_bounds__(256, DT <= 4 ? 4 : (DT == 5 ? 3 : 2)) void attn_bwd_dkdv_kernel(AParams P, const half_t* dO, int lddo,
-                                                             const float* lse, const float* Dbuf, half_t* dk,
-                                                             int lddk, half_t* dv, int lddv) {
+// KT key/value tiles (16 rows each) per wave, same sharing of the staged Q / dO / Q^T / dO^T fragments.
+template <int DT, int KT>
+__global__ __launch_bounds__(256, (KT == 1 && DT <= 4) ? 4 : ((KT == 1 && DT == 5) ? 3 : 2)) void attn_bwd_dkdv_kernel(
+    AParams P, const half_t* dO, int lddo, const float* lse, const float* Dbuf, half_t* dk, int lddk, half_t* dv,
+    int lddv) {
     constexpr int RP = DT * 16 + 8;
+    constexpr int DP = (DT + 1) / 2;
     MC_DYN_SMEM(smem);
     half_t* Qs = reinterpret_cast<half_t*>(smem);  // [64][RP]
     half_t* Os = Qs + KV_TILE * RP;                // [64][RP]   dO rows
@@ -461,35 +482,39 @@ __global__ __launch_bounds__(256, DT <= 4 ? 4 : (DT == 5 ? 3 : 2)) void attn_bwd
     const int h = blockIdx.y, b = blockIdx.z;
     const int col0 = h * P.d;
     const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)b * P.Nk;
-    const int kvi = blockIdx.x * 64 + wave * 16 + c15;
-    const bool kok = kvi < P.Nk;
+    const int k0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
+    const float sl2 = P.scale * 1.4426950408889634f;
 
     zero_pads<DT>(Qs, Qt, P.d);
     zero_pads<DT>(Os, Ot, P.d);
 
-    half4_t kf[DT], vf[DT];
+    half8_t kf8[KT][DP], vf8[KT][DP];
 #pragma unroll
-    for (int ks = 0; ks < DT; ++ks) {
-        int c = 16 * ks + 4 * g;
-        if (kok && c < P.d) {
-            kf[ks] = ld4(P.k + (kbase + kvi) * P.ldk + col0 + c);
-            vf[ks] = ld4(P.v + (kbase + kvi) * P.ldv + col0 + c);
-        } else {
-            kf[ks] = zero4();
-            vf[ks] = zero4();
+    for (int t = 0; t < KT; ++t) {
+        const int kvi = k0 + 16 * t + c15;
+        half4_t kf[2 * DP], vf[2 * DP];
+#pragma unroll
+        for (int ks = 0; ks < 2 * DP; ++ks) {
+            int c = 16 * ks + 4 * g;
+            if (kvi < P.Nk && c < P.d) {
+                kf[ks] = ld4(P.k + (kbase + kvi) * P.ldk + col0 + c);
+                vf[ks] = ld4(P.v + (kbase + kvi) * P.ldv + col0 + c);
+            } else {
+                kf[ks] = zero4();
+                vf[ks] = zero4();
+            }
+        }
+#pragma unroll
+        for (int kp = 0; kp < DP; ++kp) {
+            kf8[t][kp] = cat4(kf[2 * kp], kf[2 * kp + 1]);
+            vf8[t][kp] = cat4(vf[2 * kp], vf[2 * kp + 1]);
         }
     }
-    constexpr int DP = (DT + 1) / 2;
-    half8_t kf8[DP], vf8[DP];
+    f32x4 ak[KT][DT], av[KT][DT];
 #pragma unroll
-    for (int kp = 0; kp < DP; ++kp) {
-        kf8[kp] = cat4(kf[2 * kp], 2 * kp + 1 < DT ? kf[2 * kp + 1] : zero4());
-        vf8[kp] = cat4(vf[2 * kp], 2 * kp + 1 < DT ? vf[2 * kp + 1] : zero4());
-    }
-    const float sl2 = P.scale * 1.4426950408889634f;
-    f32x4 ak[DT], av[DT];
+    for (int t = 0; t < KT; ++t)
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) ak[dt] = av[dt] = fzero4();
+        for (int dt = 0; dt < DT; ++dt) ak[t][dt] = av[t][dt] = fzero4();
 
     for (int q0 = 0; q0 < P.Nq; q0 += KV_TILE) {
         __syncthreads();
@@ -506,11 +531,11 @@ __global__ __launch_bounds__(256, DT <= 4 ? 4 : (DT == 5 ? 3 : 2)) void attn_bwd
         __syncthreads();
 #pragma unroll
         for (int jp = 0; jp < 2; ++jp) {
-            half4_t pf[2], dsf[2];
+            half4_t pf[KT][2], dsf[KT][2];
 #pragma unroll
             for (int jj = 0; jj < 2; ++jj) {
                 const int j = 2 * jp + jj;
-                f32x4 sc = fzero4(), dp = fzero4();
+                f32x4 sc[KT], dp[KT];
                 const half_t* qrow = Qs + (16 * j + c15) * RP + 4 * g;
                 const half_t* orow = Os + (16 * j + c15) * RP + 4 * g;
 #pragma unroll
@@ -518,45 +543,58 @@ __global__ __launch_bounds__(256, DT <= 4 ? 4 : (DT == 5 ? 3 : 2)) void attn_bwd
                     const bool full = 2 * kp + 1 < DT;
                     half8_t qr = cat4(ld4(qrow + 32 * kp), full ? ld4(qrow + 32 * kp + 16) : zero4());
                     half8_t orr = cat4(ld4(orow + 32 * kp), full ? ld4(orow + 32 * kp + 16) : zero4());
-                    sc = mfma16k32(qr, kf8[kp], sc);     // [q = 16j + 4g + i][kv = c15]
-                    dp = mfma16k32(orr, vf8[kp], dp);
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {
+                        sc[t] = mfma16k32(qr, kf8[t][kp], kp == 0 ? fzero4() : sc[t]);   // [q = 16j + 4g + i][kv = c15]
+                        dp[t] = mfma16k32(orr, vf8[t][kp], kp == 0 ? fzero4() : dp[t]);
+                    }
                 }
                 const f32x4 l4 = *reinterpret_cast<const f32x4*>(lse_s + 16 * j + 4 * g);
                 const f32x4 d4 = *reinterpret_cast<const f32x4*>(D_s + 16 * j + 4 * g);
-                float pr[4], ds[4];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    pr[i] = fast_exp2(fmaf(sc[i], sl2, -l4[i]));
-                    ds[i] = pr[i] * (dp[i] - d4[i]);
+                for (int t = 0; t < KT; ++t) {
+                    float pr[4], ds[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pr[i] = fast_exp2(fmaf(sc[t][i], sl2, -l4[i]));
+                        ds[i] = pr[i] * (dp[t][i] - d4[i]);
+                    }
+                    half2_t a = pk_rtz(pr[0], pr[1]), c = pk_rtz(pr[2], pr[3]);
+                    pf[t][jj][0] = a[0]; pf[t][jj][1] = a[1]; pf[t][jj][2] = c[0]; pf[t][jj][3] = c[1];
+                    a = pk_rtz(ds[0], ds[1]); c = pk_rtz(ds[2], ds[3]);
+                    dsf[t][jj][0] = a[0]; dsf[t][jj][1] = a[1]; dsf[t][jj][2] = c[0]; dsf[t][jj][3] = c[1];
                 }
-                half2_t a = pk_rtz(pr[0], pr[1]), c = pk_rtz(pr[2], pr[3]);
-                pf[jj][0] = a[0]; pf[jj][1] = a[1]; pf[jj][2] = c[0]; pf[jj][3] = c[1];
-                a = pk_rtz(ds[0], ds[1]); c = pk_rtz(ds[2], ds[3]);
-                dsf[jj][0] = a[0]; dsf[jj][1] = a[1]; dsf[jj][2] = c[0]; dsf[jj][3] = c[1];
             }
-            const half8_t p8 = cat4(pf[0], pf[1]), ds8 = cat4(dsf[0], dsf[1]);
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 const half_t* oc = Ot + (16 * dt + c15) * TPAD + 32 * jp + 4 * g;
                 const half_t* qc = Qt + (16 * dt + c15) * TPAD + 32 * jp + 4 * g;
-                av[dt] = mfma16k32(cat4(ld4(oc), ld4(oc + 16)), p8, av[dt]);
-                ak[dt] = mfma16k32(cat4(ld4(qc), ld4(qc + 16)), ds8, ak[dt]);
+                const half8_t o8 = cat4(ld4(oc), ld4(oc + 16)), q8 = cat4(ld4(qc), ld4(qc + 16));
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    av[t][dt] = mfma16k32(o8, cat4(pf[t][0], pf[t][1]), av[t][dt]);
+                    ak[t][dt] = mfma16k32(q8, cat4(dsf[t][0], dsf[t][1]), ak[t][dt]);
+                }
             }
         }
     }
-    if (!kok) return;
 #pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-        int c = 16 * dt + 4 * g;
-        if (c < P.d) {
-            half4_t ok, ov;
+    for (int t = 0; t < KT; ++t) {
+        const int kvi = k0 + 16 * t + c15;
+        if (kvi >= P.Nk) continue;
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                ok[i] = to_half(ak[dt][i] * P.scale);
-                ov[i] = to_half(av[dt][i]);
+        for (int dt = 0; dt < DT; ++dt) {
+            int c = 16 * dt + 4 * g;
+            if (c < P.d) {
+                half4_t ok, ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ok[i] = to_half(ak[t][dt][i] * P.scale);
+                    ov[i] = to_half(av[t][dt][i]);
+                }
+                st4(dk + (kbase + kvi) * lddk + col0 + c, ok);
+                st4(dv + (kbase + kvi) * lddv + col0 + c, ov);
             }
-            st4(dk + (kbase + kvi) * lddk + col0 + c, ok);
-            st4(dv + (kbase + kvi) * lddv + col0 + c, ov);
         }
     }
 }
@@ -594,23 +632,46 @@ static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipSt
         else a_launch_fwd_cfg<DT, 1, false>(P, o, ldo, lse, s);
     }
 }
+template <int DT, int QT>
+static void a_launch_dq_cfg(const AParams& P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse,
+                            float* Dbuf, half_t* dq, int lddq, hipStream_t s) {
+    constexpr int RP = DT * 16 + 8;
+    size_t smem = (size_t)(2 * KV_TILE * RP + DT * 16 * TPAD) * sizeof(half_t);
+    dim3 grid((P.Nq + 64 * QT - 1) / (64 * QT), P.heads, P.nbatch);
+    allow_big_smem(attn_bwd_dq_kernel<DT, QT>, smem);
+    MC_LAUNCH((attn_bwd_dq_kernel<DT, QT>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
+}
+template <int DT, int KT>
+static void a_launch_dkdv_cfg(const AParams& P, const half_t* dO, int lddo, const float* lse, const float* Dbuf,
+                              half_t* dk, int lddk, half_t* dv, int lddv, hipStream_t s) {
+    constexpr int RP = DT * 16 + 8;
+    size_t smem = (size_t)(2 * KV_TILE * RP + 2 * DT * 16 * TPAD) * sizeof(half_t) + 2 * KV_TILE * sizeof(float);
+    dim3 grid((P.Nk + 64 * KT - 1) / (64 * KT), P.heads, P.nbatch);
+    allow_big_smem(attn_bwd_dkdv_kernel<DT, KT>, smem);
+    MC_LAUNCH((attn_bwd_dkdv_kernel<DT, KT>), grid, dim3(256), smem, s, P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv);
+}
+// two row tiles per wave once there are enough rows to fill the chip with the larger blocks (MC_ATTN_BQT overrides);
+// head dim 160 keeps one tile (the accumulators alone would need > 256 registers)
+static int bwd_tiles(int rows, int dt) {
+    static const int env = getenv("MC_ATTN_BQT") ? atoi(getenv("MC_ATTN_BQT")) : 0;
+    if (dt > 5) return 1;
+    return env ? env : (rows >= 512 ? 2 : 1);
+}
 template <int DT>
 static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse,
                         float* Dbuf, half_t* dq, int lddq, hipStream_t s) {
-    constexpr int RP = DT * 16 + 8;
-    size_t smem = (size_t)(2 * KV_TILE * RP + DT * 16 * TPAD) * sizeof(half_t);
-    dim3 grid((P.Nq + 63) / 64, P.heads, P.nbatch);
-    allow_big_smem(attn_bwd_dq_kernel<DT>, smem);
-    MC_LAUNCH((attn_bwd_dq_kernel<DT>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
+    if constexpr (DT <= 5) {
+        if (bwd_tiles(P.Nq, DT) == 2) return a_launch_dq_cfg<DT, 2>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
+    }
+    a_launch_dq_cfg<DT, 1>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
 }
 template <int DT>
 static void a_launch_dkdv(const AParams& P, const half_t* dO, int lddo, const float* lse, const float* Dbuf,
                           half_t* dk, int lddk, half_t* dv, int lddv, hipStream_t s) {
-    constexpr int RP = DT * 16 + 8;
-    size_t smem = (size_t)(2 * KV_TILE * RP + 2 * DT * 16 * TPAD) * sizeof(half_t) + 2 * KV_TILE * sizeof(float);
-    dim3 grid((P.Nk + 63) / 64, P.heads, P.nbatch);
-    allow_big_smem(attn_bwd_dkdv_kernel<DT>, smem);
-    MC_LAUNCH((attn_bwd_dkdv_kernel<DT>), grid, dim3(256), smem, s, P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv);
+    if constexpr (DT <= 5) {
+        if (bwd_tiles(P.Nk, DT) == 2) return a_launch_dkdv_cfg<DT, 2>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
+    }
+    a_launch_dkdv_cfg<DT, 1>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
 }
 
 #define MC_A_DISPATCH(CALL)              \
