@@ -7,7 +7,7 @@
 //   * the accumulators are staged through LDS once and leave as whole 256-byte row segments (16 B per lane,
 //     coalesced), with bias / residual / alpha - or the fused GEGLU of the feed-forward's first Linear
 //     (diffusers FeedForward, reference attention.py:211) - applied in that pass.
-#include "gemm_params.hpp"
+#include "gemm_epilogue.hpp"
 
 namespace mc {
 
@@ -188,6 +188,12 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p, uint32_t bytes
 
     // ---- epilogue: accumulators -> LDS (fp32, padded rows) -> coalesced row segments ----
     float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int TPR = BN / 8;        // threads per row, 8 columns each
+    constexpr int RPP = 256 / TPR;     // rows per store iteration
+    constexpr int NIT = BM / RPP;
+    Epilogue<TPR, RPP, NIT, CS> ep;
+    ep.init(p, tid, n0, m0, min(m0 + BM, p.M) - 1);
+    ep.prefetch(p, m0, BM);            // residual rows in flight across the staging + barrier
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
@@ -200,78 +206,7 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p, uint32_t bytes
                 *reinterpret_cast<f32x4*>(Cs + (wm0 + 32 * j + l31) * CS + wn0 + 32 * i + 8 * q + 4 * lhi) = v;
             }
     __syncthreads();
-    constexpr int TPR = BN / 8;        // threads per row, 8 columns each
-    constexpr int RPP = 256 / TPR;     // rows per pass
-    const int col = (tid % TPR) * 8;
-    const int n = n0 + col;
-    const bool vec16 = !(p.N & 7) && !(p.ldc & 7) && (!p.R || !(p.ldr & 7));
-#pragma unroll 1
-    for (int r0 = 0; r0 < BM; r0 += RPP) {
-        const int rl = r0 + tid / TPR;
-        const int m = m0 + rl;
-        if (m >= p.M || n >= p.N) continue;
-        float v[8];
-        {
-            f32x4 a = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col);
-            f32x4 b = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                v[e] = a[e];
-                v[4 + e] = b[e];
-            }
-        }
-        const int nvalid = min(8, p.N - n);  // multiple of 4
-        if (p.bias) {
-            const float* brow = p.bias + (size_t)(m / p.rows_per_batch) * p.N + n;
-            f32x4 b0 = *reinterpret_cast<const f32x4*>(brow);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += b0[e];
-            if (nvalid == 8) {
-                f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[4 + e] += b1[e];
-            }
-        }
-        if (p.epi == 1) {
-            // fused GEGLU: weight rows are interleaved (h_j, gate_j); out[m][n/2 + j] = h_j * gelu(gate_j)
-            half4_t o;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = to_half(v[2 * e] * gelu_f(v[2 * e + 1]));
-            half_t* dst = p.C + (size_t)m * p.ldc + (n >> 1);
-            if (nvalid == 8) {
-                st4(dst, o);
-            } else {
-                dst[0] = o[0];
-                dst[1] = o[1];
-            }
-            continue;
-        }
-        if (vec16) {
-            if (p.R) {
-                half8_t r = ld8(p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-            }
-            half8_t o;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-            st8(p.C + (size_t)m * p.ldc + n, o);
-        } else {
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-                if (4 * h >= nvalid) break;
-                half4_t o;
-                if (p.R) {
-                    half4_t r = ld4(p.R + (size_t)m * p.ldr + n + 4 * h);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[4 * h + e] += (float)r[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 4; ++e) o[e] = to_half(v[4 * h + e]);
-                st4(p.C + (size_t)m * p.ldc + n + 4 * h, o);
-            }
-        }
-    }
+    ep.store(p, Cs, m0, BM);
 }
 
 template <int MODE>

@@ -8,7 +8,7 @@
 // Everything else is as in gemm2.hip: operand tiles global -> LDS directly with the XOR swizzle on the source
 // address, hardware zero fill for conv padding / tails, XCD-aware tile order, accumulators leave through an LDS
 // staging tile as coalesced 16-byte row segments with the bias / residual / alpha / fused-GEGLU epilogue.
-#include "gemm_params.hpp"
+#include "gemm_epilogue.hpp"
 
 namespace mc {
 
@@ -169,12 +169,13 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
     // ---- epilogue: one wave-row (WROWS rows x BN columns) at a time through an fp32 LDS staging tile ----
     float* Cs = reinterpret_cast<float*>(smem);
     constexpr int TPR = BN / 8;
-    constexpr int RPP = NT / TPR;       // rows per pass (threads beyond RPP*TPR idle in the store phase)
-    const int col = (tid % TPR) * 8;
-    const int n = n0 + col;
-    const bool vec16 = !(p.N & 7) && !(p.ldc & 7) && (!p.R || !(p.ldr & 7));
+    constexpr int RPP = NT / TPR;       // rows per store iteration (threads beyond RPP*TPR idle in the store phase)
+    constexpr int NIT = (WROWS + RPP - 1) / RPP;
+    Epilogue<TPR, RPP, NIT, CS> ep;
+    ep.init(p, tid, n0, m0, min(m0 + BM, p.M) - 1);
 #pragma unroll 1
     for (int pass = 0; pass < NWM; ++pass) {
+        ep.prefetch(p, m0 + pass * WROWS, WROWS);   // residual rows in flight across the staging + barrier
         if (wr == pass) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
@@ -189,74 +190,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
                     }
         }
         __syncthreads();
-        if (tid < RPP * TPR && n < p.N) {
-#pragma unroll 1
-            for (int r0 = 0; r0 < WROWS; r0 += RPP) {
-                const int rl = r0 + tid / TPR;
-                const int m = m0 + pass * WROWS + rl;
-                if (rl >= WROWS || m >= p.M) continue;
-                float v[8];
-                {
-                    f32x4 a = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col);
-                    f32x4 b = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col + 4);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        v[e] = a[e];
-                        v[4 + e] = b[e];
-                    }
-                }
-                const int nvalid = min(8, p.N - n);
-                if (p.bias) {
-                    const float* brow = p.bias + (size_t)(m / p.rows_per_batch) * p.N + n;
-                    f32x4 b0 = *reinterpret_cast<const f32x4*>(brow);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b0[e];
-                    if (nvalid == 8) {
-                        f32x4 b1 = *reinterpret_cast<const f32x4*>(brow + 4);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) v[4 + e] += b1[e];
-                    }
-                }
-                if (p.epi == 1) {
-                    half4_t o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[2 * e] * gelu_f(v[2 * e + 1]));
-                    half_t* dst = p.C + (size_t)m * p.ldc + (n >> 1);
-                    if (nvalid == 8) {
-                        st4(dst, o);
-                    } else {
-                        dst[0] = o[0];
-                        dst[1] = o[1];
-                    }
-                    continue;
-                }
-                if (vec16) {
-                    if (p.R) {
-                        half8_t r = ld8(p.R + (size_t)m * p.ldr + n);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] += (float)r[e];
-                    }
-                    half8_t o;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                    st8(p.C + (size_t)m * p.ldc + n, o);
-                } else {
-#pragma unroll
-                    for (int h = 0; h < 2; ++h) {
-                        if (4 * h >= nvalid) break;
-                        half4_t o;
-                        if (p.R) {
-                            half4_t r = ld4(p.R + (size_t)m * p.ldr + n + 4 * h);
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) v[4 * h + e] += (float)r[e];
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) o[e] = to_half(v[4 * h + e]);
-                        st4(p.C + (size_t)m * p.ldc + n + 4 * h, o);
-                    }
-                }
-            }
-        }
+        ep.store(p, Cs, m0 + pass * WROWS, WROWS);
         __syncthreads();
     }
 }
