@@ -260,6 +260,8 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
     p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
     p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi;
+    static const int dbg_env = getenv("MC_GEMM_DEBUG") ? atoi(getenv("MC_GEMM_DEBUG")) : 0;
+    p.dbg = dbg_env;
     int small_tile = tile == 64;
     if (tile == 0) {
         // heuristic: fall to 64x64 tiles when 128x128 would leave most of the 256 CUs idle

@@ -12,22 +12,45 @@
 
 namespace mc {
 
-template <int MODE, int BM, int BN, int NWM, int NWN>
-__global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
-                                                                uint32_t bytesW, int tilesM, int tilesN) {
+// byte offset of 16-byte slot v of a row of BKT halfs; slots XOR-swizzled so that every 16-lane group of a
+// ds_read_b128 (rows l31, fixed logical slot) covers all 64 banks: 128-byte rows by (row>>1)&7, 64-byte rows by
+// (row>>2)&3 (rows {r, 12+r, 20+r, 24+r} of a lane group then take the four distinct slots of their bank quarter)
+template <int BKT>
+__device__ __forceinline__ int lds_off_t(int row, int v) {
+    if (BKT == 64) return row * 128 + ((v ^ ((row >> 1) & 7)) << 4);
+    return row * 64 + ((v ^ ((row >> 2) & 3)) << 4);
+}
+
+// BKT: K depth of one staged tile (64, or 32 to halve the operand LDS so that two workgroups share a CU and one's
+//      epilogue stores overlap the other's MFMAs - the K = 320 GEMMs spend half their time in the epilogue).
+// PJ:  32-row accumulator sub-tiles written per epilogue pass (TM = all of a wave-row at once, 1 = small staging tile).
+// WPE: minimum waves per SIMD the register allocation must allow.
+// NS:  LDS stages.  2 = load tile k+1 while computing k (one __syncthreads per tile); >= 3 = ring with NS-1 tiles in
+//      flight, counted vmcnt waits and one raw barrier per tile: a k-step of the 2-stage loop measures ~2.3 us
+//      against ~1.1 us of MFMA work because each step exposes the full LDS-DMA landing latency.
+template <int MODE, int BM, int BN, int NWM, int NWN, int BKT, int PJ, int WPE, int NS>
+__global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm3_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
+                                                                     uint32_t bytesW, int tilesM, int tilesN) {
     constexpr int NW = NWM * NWN;
     constexpr int NT = 64 * NW;
     constexpr int TM = BM / NWM / 32;
     constexpr int TN = BN / NWN / 32;
-    constexpr int RA = BM / 8 / NW;  // 8-row groups staged per wave
-    constexpr int RW = BN / 8 / NW;
-    constexpr int WROWS = BM / NWM;  // rows of one wave-row = rows of one epilogue pass
+    constexpr int ROWB = BKT * 2;        // bytes per staged row
+    constexpr int SPR = ROWB / 16;       // 16-byte slots per row
+    constexpr int RPI = 64 / SPR;        // rows moved by one wave-wide LDS-DMA instruction (1 KiB)
+    constexpr int RA = BM / RPI / NW;    // row groups staged per wave
+    constexpr int RWLO = BN / RPI / NW;  // weight row groups per wave; the first EXTRA waves take one more
+    constexpr int EXTRA = (BN / RPI) % NW;
+    constexpr int RW = RWLO + (EXTRA ? 1 : 0);
+    constexpr int WROWS = 32 * PJ;       // rows of one epilogue pass
     constexpr int CS = BN + 4;
-    static_assert(BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0 && BM % (8 * NW) == 0 && BN % (8 * NW) == 0, "tile");
+    static_assert(BM % (32 * NWM) == 0 && BN % (32 * NWN) == 0 && BM % (RPI * NW) == 0 && BN % RPI == 0, "tile");
+    static_assert(NS >= 2 && (EXTRA == 0 || NS > 2), "uneven weight staging needs the counted-wait ring");
     static_assert(NW % 2 == 0, "swizzle constant assumes an even wave count");
+    static_assert(TM % PJ == 0 && (BKT == 64 || BKT == 32), "epilogue pass / K depth");
     MC_DYN_SMEM(smem);
-    char* sA = smem;                  // [2][BM][128 B]
-    char* sW = smem + 2 * BM * 128;   // [2][BN][128 B]
+    char* sA = smem;                    // [NS][BM][ROWB]
+    char* sW = smem + NS * BM * ROWB;   // [NS][BN][ROWB]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -43,14 +66,14 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
     const GBuf bufA2 = make_gbuf(p.A2 ? p.A2 : p.A, p.A2 ? bytesA2 : bytesA);
     const GBuf bufW = make_gbuf(p.W, bytesW);
 
-    const int rsub = lane >> 3;
-    const int sw = (((wave & 1) << 2) | (lane >> 4)) & 7;
-    const int lslot = (lane & 7) ^ sw;
+    // lane -> (row within the instruction's row group, physical slot); the logical slot it must fetch undoes the swizzle
+    const int rsub = lane / SPR;
+    const int lslot = BKT == 64 ? ((lane & 7) ^ ((((wave & 1) << 2) | (lane >> 4)) & 7)) : ((lane & 3) ^ (lane >> 4));
 
     int a_valid[RA], a_pix[RA], a_oy[RA], a_ox[RA];
 #pragma unroll
     for (int i = 0; i < RA; ++i) {
-        int m = m0 + (wave + NW * i) * 8 + rsub;
+        int m = m0 + (wave + NW * i) * RPI + rsub;
         a_valid[i] = m < p.M;
         if (MODE == DENSE) {
             a_pix[i] = m;
@@ -65,20 +88,22 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
             a_ox[i] = rem - oy * p.Wo;
         }
     }
+    const bool w_hi = EXTRA == 0 || wave < EXTRA;   // this wave stages RW (not RW-1) weight row groups
     uint32_t w_off[RW];
 #pragma unroll
     for (int i = 0; i < RW; ++i) {
-        int n = n0 + (wave + NW * i) * 8 + rsub;
+        int n = n0 + (wave + NW * i) * RPI + rsub;
         w_off[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)lslot * 16u : kOOB;
     }
 
     auto issue_tiles = [&](int kt, int buf) {
-        const int k0 = kt * BK;
+        const int k0 = kt * BKT;
         int tap = 0, c0 = k0;
         if (MODE != DENSE) {  // K order: 64-channel tile major, tap minor (the 9 taps of a channel tile are adjacent)
-            const int ct = kt / 9;
-            tap = kt - 9 * ct;
-            c0 = ct * BK;
+            const int kt64 = BKT == 64 ? kt : kt >> 1;
+            const int ct = kt64 / 9;
+            tap = kt64 - 9 * ct;
+            c0 = ct * 64 + (BKT == 64 ? 0 : (kt & 1) * 32);
         }
         const bool second = c0 >= p.c1;
         const int ld = second ? p.lda2 : p.lda;
@@ -115,7 +140,7 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
                 row = a_pix[i] + iy * p.Ws + ix;
             }
             uint32_t voff = ok ? ((uint32_t)row * (uint32_t)ld + (uint32_t)cc) * 2u : kOOB;
-            char* dst = sA + buf * BM * 128 + (wave + NW * i) * 1024;
+            char* dst = sA + buf * BM * ROWB + (wave + NW * i) * 1024;
             if (second)
                 glds16(bufA2, voff, dst);
             else
@@ -123,8 +148,22 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
         }
 #pragma unroll
         for (int i = 0; i < RW; ++i) {
+            if (i == RW - 1 && !w_hi) break;   // wave-uniform
             uint32_t voff = w_off[i] == kOOB ? kOOB : w_off[i] + (uint32_t)k0 * 2u;
-            glds16(bufW, voff, sW + buf * BN * 128 + (wave + NW * i) * 1024);
+            glds16(bufW, voff, sW + buf * BN * ROWB + (wave + NW * i) * 1024);
+        }
+    };
+    // wait until at most `tiles` of this wave's staged tiles are still in flight (vmcnt retires in order)
+    auto wait_tiles = [&](int tiles) {
+        constexpr int LHI = RA + RW, LLO = RA + RW - 1;
+        if (tiles <= 0) {
+            wait_vmcnt_le<0>();
+        } else if (tiles == 1) {
+            if (w_hi) wait_vmcnt_le<LHI>(); else wait_vmcnt_le<LLO>();
+        } else if (tiles == 2) {
+            if (w_hi) wait_vmcnt_le<2 * LHI>(); else wait_vmcnt_le<2 * LLO>();
+        } else {
+            if (w_hi) wait_vmcnt_le<3 * LHI>(); else wait_vmcnt_le<3 * LLO>();
         }
     };
 
@@ -141,52 +180,104 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
     const int wn0 = wc * (32 * TN);
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    const int nk = p.K / BK;
-    issue_tiles(0, 0);
-    __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_tiles(kt + 1, buf ^ 1);
-        const char* bA = sA + buf * BM * 128;
-        const char* bW = sW + buf * BN * 128;
+    const int nk = (p.dbg & 2) ? 0 : p.K / BKT;
+    if (p.dbg & 4) return;
+    if (NS == 2) {
+        if (nk) issue_tiles(0, 0);
+        __syncthreads();
+    } else {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            half8_t fa[TM], fw[TN];
+        for (int s0 = 0; s0 < NS - 1; ++s0)
+            if (s0 < nk) issue_tiles(s0, s0);
+    }
+    int buf = 0;
+    for (int kt = 0; kt < nk; ++kt) {
+        if (NS == 2) {
+            if (kt + 1 < nk) issue_tiles(kt + 1, buf ^ 1);
+        } else {
+            // tile kt landed (own loads: counted wait; everybody's: barrier).  Past the barrier every wave is also done
+            // reading stage (kt-1) % NS, which the tile issued next overwrites.
+            wait_tiles(min(NS - 2, nk - 1 - kt));
+            raw_barrier();
+            if (kt + NS - 1 < nk) issue_tiles(kt + NS - 1, buf == 0 ? NS - 1 : buf - 1);
+        }
+        const char* bA = sA + buf * BM * ROWB;
+        const char* bW = sW + buf * BN * ROWB;
+        // fragments of k-slice ks+1 are requested before the MFMAs of slice ks are issued (two register sets), so the
+        // ~100+ cycle ds_read latency runs under 10 MFMAs instead of draining the matrix pipe at every wait
+        half8_t fa[2][TM], fw[2][TN];
+        auto load_frags = [&](int ks, half8_t* a, half8_t* w) {
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                fa[j] = *reinterpret_cast<const half8_t*>(bA + lds_off(wm0 + 32 * j + l31, 2 * ks + lhi));
+                a[j] = *reinterpret_cast<const half8_t*>(bA + lds_off_t<BKT>(wm0 + 32 * j + l31, 2 * ks + lhi));
 #pragma unroll
             for (int i = 0; i < TN; ++i)
-                fw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off(wn0 + 32 * i + l31, 2 * ks + lhi));
+                w[i] = *reinterpret_cast<const half8_t*>(bW + lds_off_t<BKT>(wn0 + 32 * i + l31, 2 * ks + lhi));
+        };
+        load_frags(0, fa[0], fw[0]);
+#pragma unroll
+        for (int ks = 0; ks < BKT / 16; ++ks) {
+            if (ks + 1 < BKT / 16) load_frags(ks + 1, fa[(ks + 1) & 1], fw[(ks + 1) & 1]);
 #pragma unroll
             for (int i = 0; i < TN; ++i)
 #pragma unroll
-                for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(fw[i], fa[j], acc[i][j]);
+                for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(fw[ks & 1][i], fa[ks & 1][j], acc[i][j]);
+#ifndef MC_EMU
+            // pin the interleave: one fragment read of the next slice behind each of the first TM+TN MFMAs
+            if (ks + 1 < BKT / 16) {
+#pragma unroll
+                for (int r = 0; r < TM + TN; ++r) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // MFMA
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   // DS read
+                }
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN - TM - TN, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, TM * TN, 0);
+            }
+#endif
         }
-        __syncthreads();
+        if (NS == 2) {
+            __syncthreads();
+            buf ^= 1;
+        } else {
+            buf = buf == NS - 1 ? 0 : buf + 1;
+        }
     }
+    if (NS > 2) __syncthreads();  // all fragment reads done before the staging tile overwrites the operands
 
-    // ---- epilogue: one wave-row (WROWS rows x BN columns) at a time through an fp32 LDS staging tile ----
+    // ---- epilogue: WROWS rows x BN columns at a time through an fp32 LDS staging tile ----
     float* Cs = reinterpret_cast<float*>(smem);
     constexpr int TPR = BN / 8;
     constexpr int RPP = NT / TPR;       // rows per store iteration (threads beyond RPP*TPR idle in the store phase)
     constexpr int NIT = (WROWS + RPP - 1) / RPP;
+    constexpr int NPASS = BM / WROWS;
+    constexpr int PPW = TM / PJ;        // passes per wave-row
     Epilogue<TPR, RPP, NIT, CS> ep;
     ep.init(p, tid, n0, m0, min(m0 + BM, p.M) - 1);
 #pragma unroll 1
-    for (int pass = 0; pass < NWM; ++pass) {
+    for (int pass = 0; pass < NPASS; ++pass) {
         ep.prefetch(p, m0 + pass * WROWS, WROWS);   // residual rows in flight across the staging + barrier
-        if (wr == pass) {
+        if (wr == pass / PPW) {
+            const int jb = (pass % PPW) * PJ;
 #pragma unroll
-            for (int j = 0; j < TM; ++j)
+            for (int jj = 0; jj < PJ; ++jj)
 #pragma unroll
                 for (int i = 0; i < TN; ++i)
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         f32x4 v;
+                        if (PJ == TM) {
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-                        *reinterpret_cast<f32x4*>(Cs + (32 * j + l31) * CS + wn0 + 32 * i + 8 * q + 4 * lhi) = v;
+                            for (int e = 0; e < 4; ++e) v[e] = acc[i][jj][4 * q + e] * p.alpha;
+                        } else {   // runtime sub-tile index: select without dynamic register indexing
+#pragma unroll
+                            for (int j = 0; j < TM; ++j)
+                                if (j == jb + jj) {
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                                }
+                        }
+                        *reinterpret_cast<f32x4*>(Cs + (32 * jj + l31) * CS + wn0 + 32 * i + 8 * q + 4 * lhi) = v;
                     }
         }
         __syncthreads();
@@ -195,26 +286,31 @@ __global__ __launch_bounds__(64 * NWM * NWN) void gemm3_kernel(GemmParams p, uin
     }
 }
 
-template <int MODE, int BM, int BN, int NWM, int NWN>
+template <int MODE, int BM, int BN, int NWM, int NWN, int BKT, int PJ, int WPE, int NS>
 static int launch3(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
     int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
-    size_t operands = (size_t)2 * (BM + BN) * 128;
-    size_t staging = (size_t)(BM / NWM) * (BN + 4) * 4;
+    size_t operands = (size_t)NS * (BM + BN) * BKT * 2;
+    size_t staging = (size_t)(32 * PJ) * (BN + 4) * 4;
     size_t smem = operands > staging ? operands : staging;
-    allow_big_smem(gemm3_kernel<MODE, BM, BN, NWM, NWN>, smem);
+    allow_big_smem(gemm3_kernel<MODE, BM, BN, NWM, NWN, BKT, PJ, WPE, NS>, smem);
     dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN));
-    MC_LAUNCH((gemm3_kernel<MODE, BM, BN, NWM, NWN>), grid, dim3(64 * NWM * NWN), smem, stream, p, bA, bA2, bW, tM, tN);
+    MC_LAUNCH((gemm3_kernel<MODE, BM, BN, NWM, NWN, BKT, PJ, WPE, NS>), grid, dim3(64 * NWM * NWN), smem, stream, p, bA,
+              bA2, bW, tM, tN);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
 template <int MODE>
 static int launch3_cfg(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, int cfg, hipStream_t s) {
     switch (cfg) {
-        case 1: return launch3<MODE, 256, 320, 4, 2>(p, bA, bA2, bW, s);   // wave 64 x 160
-        case 2: return launch3<MODE, 256, 256, 4, 2>(p, bA, bA2, bW, s);   // wave 64 x 128
-        case 3: return launch3<MODE, 256, 128, 4, 2>(p, bA, bA2, bW, s);   // wave 64 x 64
-        case 4: return launch3<MODE, 128, 320, 2, 2>(p, bA, bA2, bW, s);   // 4 waves, wave 64 x 160
-        case 5: return launch3<MODE, 128, 256, 2, 4>(p, bA, bA2, bW, s);   // wave 64 x 64
+        case 1: return launch3<MODE, 256, 320, 4, 2, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // 8 waves, wave 64 x 160
+        case 2: return launch3<MODE, 256, 256, 4, 2, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // wave 64 x 128
+        case 3: return launch3<MODE, 256, 128, 4, 2, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // wave 64 x 64
+        case 4: return launch3<MODE, 128, 320, 2, 2, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // 4 waves, wave 64 x 160
+        case 5: return launch3<MODE, 128, 256, 2, 4, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // wave 64 x 64
+        case 6: return launch3<MODE, 128, 320, 2, 2, 32, 1, 2, 2>(p, bA, bA2, bW, s);   // 4 waves, K depth 32: 2 blocks / CU
+        case 7: return launch3<MODE, 256, 320, 4, 2, 32, 2, 1, 4>(p, bA, bA2, bW, s);   // cfg 1 as a 4-stage ring of K-32 tiles
+        case 8: return launch3<MODE, 128, 320, 2, 2, 32, 1, 2, 3>(p, bA, bA2, bW, s);   // cfg 6 with a 3-stage ring (84 KiB: 1 block / CU)
+        case 9: return launch3<MODE, 256, 256, 4, 2, 32, 2, 1, 4>(p, bA, bA2, bW, s);   // cfg 2 as a 4-stage ring
         default: return MC_ERR_UNSUPPORTED;
     }
 }

@@ -81,6 +81,7 @@ struct Epilogue {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) o[e] = to_half(v[2 * e] * gelu_f(v[2 * e + 1]));
                 half_t* dst = p.C + (size_t)m * p.ldc + (n >> 1);
+                if (p.dbg & 1) continue;
                 if (nvalid == 8) {
                     st4(dst, o);
                 } else {
@@ -97,7 +98,7 @@ struct Epilogue {
                 half8_t o;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                st8(p.C + (size_t)m * p.ldc + n, o);
+                if (!(p.dbg & 1)) st8(p.C + (size_t)m * p.ldc + n, o);
             } else {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {

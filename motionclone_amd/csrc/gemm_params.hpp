@@ -24,6 +24,7 @@ struct GemmParams {
     int rows_per_batch;
     float alpha;
     int epi;    // 0: bias/residual epilogue, 1: fused GEGLU (v2 kernel only)
+    int dbg;    // timing experiments only (MC_GEMM_DEBUG): 1 = no global stores, 2 = no k-loop, 4 = no epilogue
 };
 
 constexpr int BK = 64;

@@ -38,7 +38,7 @@ def v1(request):
     return request.param
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9])
 def test_gemm_large_tile_geometries(backend, cfg):
     """gemm3.hip: every block geometry, dense with bias/residual/tails, conv with concat, fused GEGLU"""
     dev = backend
