@@ -33,10 +33,12 @@ TFLOP_GUIDED, TFLOP_PLAIN, TFLOP_EXTRACT = 45.50, 35.35, 10.06
 PEAK_FP16_MFMA_TFLOPS = 2500.0
 
 
-def gemm_kernel_name(mode, M, N):
+def gemm_kernel_name(mode, M, N, K=0):
     """Which kernel instance mc_gemm_f16 picks in auto mode (mirrors the heuristic in csrc/gemm.hip)."""
     modes = {ops.DENSE: "DENSE", ops.CONV_S1: "CONV_S1", ops.CONV_S2: "CONV_S2", ops.CONV_UP: "CONV_UP",
              ops.TCONV_S2: "TCONV_S2"}
+    if K and lib.load().mc_gemm_splitk_plan(M, N, K, mode) > 1:
+        return "gemm3_kernel<%s,128,320,2,2> split-K + reduce" % modes[mode]
     if N % 320 == 0:
         if ((M + 255) // 256) * (N // 320) >= 224:
             return "gemm3_kernel<%s,256,320,4,2>" % modes[mode]
@@ -73,7 +75,7 @@ class GemmProbe:
             # algorithmic bytes: every operand once (activations, weights, residual, output)
             nbytes = 2.0 * (a.shape[0] * a.shape[1] + (kw["a2"].numel() if kw.get("a2") is not None else 0)
                             + N * K + M * n_out * (2 if kw.get("residual") is not None else 1))
-            probe.events.append((gemm_kernel_name(mode, M, N), e0, e1, 2.0 * M * N * K, nbytes))
+            probe.events.append((gemm_kernel_name(mode, M, N, K), e0, e1, 2.0 * M * N * K, nbytes))
             return out
         ops.gemm = gemm
 

@@ -46,6 +46,16 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
 
+/* Split-K variant for small-M / deep-K problems (the 8x8 and 16x16-level 3x3 convs of unet_blocks.py:Downsample3D /
+ * ResnetBlock3D at reference motionclone/models/resnet.py:110-209): K is cut into `splits` ranges computed by
+ * separate workgroups into the fp32 workspace ws[splits][M][N]; a reduce kernel applies bias / residual.
+ * mc_gemm_splitk_plan returns the number of ranges to use for a problem (1 = call mc_gemm_f16 instead). */
+int mc_gemm_splitk_plan(int M, int N, int K, int mode);
+int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
+                       int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode, int Hs,
+                       int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, float* ws, int splits,
+                       void* stream);
+
 /* ---- GroupNorm(32) [+SiLU] ------------------------------------------------------------------
  * resnet.py:21-29,186-187,197-203; attention.py:61,105; motion_module.py:112,145; unet.py:245.
  * Two-source input (a: channels [0,c1), b: [c1,ctot)).  partial: float[frames*mc_gn_nchunk(hw)*64]

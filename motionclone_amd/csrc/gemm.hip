@@ -262,6 +262,8 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
     p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi;
     static const int dbg_env = getenv("MC_GEMM_DEBUG") ? atoi(getenv("MC_GEMM_DEBUG")) : 0;
     p.dbg = dbg_env;
+    p.ws = nullptr;
+    p.splits = 1;
     int small_tile = tile == 64;
     if (tile == 0) {
         // heuristic: fall to 64x64 tiles when 128x128 would leave most of the 256 CUs idle
@@ -294,4 +296,93 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
         case CONV_UP: return launch_mode<CONV_UP>(p, small_tile, s);
         default: return launch_mode<TCONV_S2>(p, small_tile, s);
     }
+}
+
+// ---- split-K ------------------------------------------------------------------------------------------------------
+namespace mc {
+// out[m][n..n+3] = sum_s ws[s][m][n..] + bias[m / rows_per_batch][n..] + R[m][n..]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, half_t* C, int ldc,
+                                                            const half_t* R, int ldr, const float* bias, int M, int N,
+                                                            int rows_per_batch) {
+    const int nv = N / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * nv) return;
+    const int m = (int)(idx / nv), n = (int)(idx - (long)m * nv) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+    for (int s = 1; s < splits; ++s) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(ws + ((size_t)s * M + m) * N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += x[e];
+    }
+    if (bias) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(bias + (size_t)(m / rows_per_batch) * N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+    }
+    if (R) {
+        half4_t r = ld4(R + (size_t)m * ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    half4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+    st4(C + (size_t)m * ldc + n, o);
+}
+}  // namespace mc
+
+// How many K ranges mc_gemm_splitk_f16 should be given for this problem (1 = use mc_gemm_f16).  Policy, measured on
+// MI355X: the 8x8 / 16x16-level 3x3 convs (M <= 4096 rows, K = 11520 or 23040) leave 128x320 tiles on a fraction of
+// the CUs or fall to 64x64 tiles at ~300 TFLOP/s; splitting K over up to 8 workgroups per tile fills the chip with
+// the efficient geometry and costs one fp32 round trip of the (small) output (8x8 level: 143 -> 95 us at B = 2,
+// 123 -> 60 us at B = 1; 16x16 level at B = 1: 189 -> 153 us).
+extern "C" int mc_gemm_splitk_plan(int M, int N, int K, int mode) {
+    (void)mode;
+    if (N % 320 || K < 2304 || M <= 0) return 1;
+    long tiles = (long)((M + 127) / 128) * (N / 320);
+    if (tiles >= 256) return 1;
+    int s = (int)(256 / tiles);
+    if (s > 8) s = 8;
+    while (s > 1 && (K / BK) / s < 8) --s;
+    return s < 2 ? 1 : s;
+}
+
+// Same contract as mc_gemm_f16 (no GEGLU epilogue), K split into `splits` ranges.  ws: fp32 workspace of
+// splits * M * N elements.  flags bits 12-15 choose the gemm3 geometry (default 4: 128x320 tiles).
+extern "C" int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
+                                  const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1,
+                                  int ctot, int mode, int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha,
+                                  int flags, float* ws, int splits, void* stream) {
+    int cfg = (flags >> 12) & 0xF;
+    if (!cfg) cfg = 4;
+    if (M <= 0 || N <= 0 || K <= 0 || !ws || splits < 1) return MC_ERR_SHAPE;
+    if (flags & 0x200) return MC_ERR_UNSUPPORTED;
+    if (cfg > 6) return MC_ERR_UNSUPPORTED;   // two-stage geometries only
+    if (K % BK || N % 4 || ldc % 4 || (R && (ldr % 4))) return MC_ERR_SHAPE;
+    if (lda % 8 || (A2 && lda2 % 8)) return MC_ERR_SHAPE;
+    if (mode < 0 || mode > 4) return MC_ERR_UNSUPPORTED;
+    if (mode == DENSE) ctot = K;
+    if (ctot <= 0 || ctot % BK || c1 % BK || c1 > ctot) return MC_ERR_SHAPE;
+    if (c1 < ctot && !A2) return MC_ERR_SHAPE;
+    if (mode != DENSE) {
+        if (K != 9 * ctot || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return MC_ERR_SHAPE;
+        if (M % (Ho * Wo)) return MC_ERR_SHAPE;
+    }
+    if (splits > K / BK) splits = K / BK;
+    if (rows_per_batch <= 0) rows_per_batch = M;
+    GemmParams p;
+    p.A = (const half_t*)A; p.A2 = (const half_t*)A2; p.W = (const half_t*)W;
+    p.C = (half_t*)C; p.R = nullptr; p.bias = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
+    p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
+    p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = 0; p.dbg = 0;
+    p.ws = ws; p.splits = splits;
+    hipStream_t s = (hipStream_t)stream;
+    size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
+    int rc = gemm3_dispatch(p, mode, cfg, rowsA, s);
+    if (rc != MC_OK) return rc;
+    long nthr = (long)M * (N / 4);
+    MC_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, ws, splits, (half_t*)C, ldc,
+              (const half_t*)R, ldr, bias, M, N, rows_per_batch);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }

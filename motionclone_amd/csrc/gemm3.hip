@@ -180,18 +180,23 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm3_kernel(GemmParams p
     const int wn0 = wc * (32 * TN);
     const int l31 = lane & 31, lhi = lane >> 5;
 
-    const int nk = (p.dbg & 2) ? 0 : p.K / BKT;
+    // split-K: grid.y K ranges of (almost) equal length; the kernel is otherwise unchanged, its epilogue stores raw
+    // fp32 partial sums and a reduce kernel applies bias / residual (small-M, deep-K convs of the 8x8 / 16x16 levels)
+    const int split = blockIdx.y;
+    const int nk_all = p.K / BKT;
+    const int kt_begin = (int)((long)split * nk_all / p.splits);
+    const int nk = (p.dbg & 2) ? 0 : (int)((long)(split + 1) * nk_all / p.splits);
     if (p.dbg & 4) return;
     if (NS == 2) {
-        if (nk) issue_tiles(0, 0);
+        if (nk > kt_begin) issue_tiles(kt_begin, 0);
         __syncthreads();
     } else {
 #pragma unroll
         for (int s0 = 0; s0 < NS - 1; ++s0)
-            if (s0 < nk) issue_tiles(s0, s0);
+            if (kt_begin + s0 < nk) issue_tiles(kt_begin + s0, s0);
     }
     int buf = 0;
-    for (int kt = 0; kt < nk; ++kt) {
+    for (int kt = kt_begin; kt < nk; ++kt) {
         if (NS == 2) {
             if (kt + 1 < nk) issue_tiles(kt + 1, buf ^ 1);
         } else {
@@ -281,7 +286,10 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm3_kernel(GemmParams p
                     }
         }
         __syncthreads();
-        ep.store(p, Cs, m0 + pass * WROWS, WROWS);
+        if (p.ws)
+            ep.store_partial(p, Cs, m0 + pass * WROWS, WROWS, split);
+        else
+            ep.store(p, Cs, m0 + pass * WROWS, WROWS);
         __syncthreads();
     }
 }
@@ -293,7 +301,7 @@ static int launch3(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, 
     size_t staging = (size_t)(32 * PJ) * (BN + 4) * 4;
     size_t smem = operands > staging ? operands : staging;
     allow_big_smem(gemm3_kernel<MODE, BM, BN, NWM, NWN, BKT, PJ, WPE, NS>, smem);
-    dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN));
+    dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN), (unsigned)p.splits);
     MC_LAUNCH((gemm3_kernel<MODE, BM, BN, NWM, NWN, BKT, PJ, WPE, NS>), grid, dim3(64 * NWM * NWN), smem, stream, p, bA,
               bA2, bW, tM, tN);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;

@@ -56,6 +56,19 @@ struct Epilogue {
             if (rl < rows && m < p.M) rres[it] = ld8(p.R + (size_t)m * p.ldr + n);
         }
     }
+    // split-K: raw fp32 partial sums of this K range -> ws[split][m][n] (two 16-byte stores per segment)
+    __device__ __forceinline__ void store_partial(const GemmParams& p, const float* Cs, int m_base, int rows, int split) {
+        if (!active) return;
+        float* ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int rl = it * RPP + rsub, m = m_base + rl;
+            if (rl >= rows || m >= p.M) continue;
+            float* dst = ws + (size_t)m * p.N + n;
+            *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col);
+            if (nvalid == 8) *reinterpret_cast<f32x4*>(dst + 4) = *reinterpret_cast<const f32x4*>(Cs + rl * CS + col + 4);
+        }
+    }
     __device__ __forceinline__ void store(const GemmParams& p, const float* Cs, int m_base, int rows) {
         if (!active) return;
 #pragma unroll

@@ -20,6 +20,8 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 SIGNATURES = {
     "mc_version": [],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
+    "mc_gemm_splitk_plan": [I, I, I, I],
+    "mc_gemm_splitk_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P, I, P],
     "mc_gn_nchunk": [I],
     "mc_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, F, P, P, P],
     "mc_groupnorm_apply_f16": [P, P, I, I, I, I, I, I, P, P, P, P, I, I, P],

@@ -47,11 +47,12 @@ def empty(shape, like, dtype=torch.float16):
 
 # ---- GEMM family ---------------------------------------------------------------------------------
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
-         rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0):
+         rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0, splits=None):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
 
     geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
-    geglu=True: w rows interleaved (h_j, gate_j) (see `interleave_geglu`), out gets N/2 columns h*gelu(gate)."""
+    geglu=True: w rows interleaved (h_j, gate_j) (see `interleave_geglu`), out gets N/2 columns h*gelu(gate).
+    splits: K ranges for the split-K path (None = the library's plan, 1 = off)."""
     _f16(a), _f16(w)
     N, K = w.shape
     c1 = a.shape[1]
@@ -72,6 +73,14 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N
+    if splits is None:
+        splits = 1 if (geglu or tile or v1 or deep or cfg) else lib.load().mc_gemm_splitk_plan(M, N, K, mode)
+    if splits > 1:
+        ws = empty((splits * M * N,), a, torch.float32)
+        lib.call("mc_gemm_splitk_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
+                 _ld(a2), _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha),
+                 flags, _p(ws), splits, _stream(a))
+        return out
     lib.call("mc_gemm_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a), _ld(a2),
              _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha), flags,
              _stream(a))

@@ -60,6 +60,35 @@ def test_gemm_large_tile_geometries(backend, cfg):
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm3 geglu")
 
 
+@pytest.mark.parametrize("splits,cfg", [(2, 0), (3, 4), (5, 1), (4, 6)])
+def test_gemm_split_k(backend, splits, cfg):
+    """split-K path: K ranges in separate workgroups -> fp32 partial sums -> reduce kernel with bias / residual"""
+    dev = backend
+    M, N, K = (200, 328, 448) if not big(dev) else (2048, 1280, 2880)
+    a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+    bias = torch.randn(2, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    res = rnd((M, N), dev, 4)
+    out = ops.gemm(a, w, bias=bias, residual=res, alpha=0.5, rows_per_batch=M // 2, cfg=cfg, splits=splits)
+    ref = 0.5 * (a.float() @ w.float().t()) + bias.repeat_interleave(M // 2, 0) + res.float()
+    close(out, ref, 2e-2, 5e-3, "split-K dense")
+    NF, Cin, Cout, H, W = (2, 64, 72, 6, 10) if not big(dev) else (32, 1280, 1280, 8, 8)
+    x, x2 = rnd((NF, Cin, H, W), dev, 5), rnd((NF, 64, H, W), dev, 6)
+    wc = rnd((Cout, Cin + 64, 3, 3), dev, 7, 0.05 if not big(dev) else 0.01)
+    o = ops.gemm(_to_cl(x), _conv_w_pack(wc), a2=_to_cl(x2), mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W,
+                 cfg=cfg, splits=splits)
+    close(_from_cl(o, NF, H, W), Fn.conv2d(torch.cat([x, x2], 1).float(), wc.float(), padding=1), 3e-2, 5e-3, "split-K conv")
+
+
+def test_gemm_split_k_plan(backend):
+    from motionclone_amd import lib
+    L = lib.load()
+    assert L.mc_gemm_splitk_plan(2048, 1280, 11520, 1) == 4      # 8x8 level, B = 2: 64 tiles -> 4 ranges
+    assert L.mc_gemm_splitk_plan(1024, 1280, 23040, 1) == 8
+    assert L.mc_gemm_splitk_plan(131072, 320, 2880, 1) == 1      # plenty of tiles
+    assert L.mc_gemm_splitk_plan(2048, 1280, 1280, 0) == 1       # K too shallow
+    assert L.mc_gemm_splitk_plan(2048, 1000, 11520, 0) == 1      # N not a multiple of 320
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(300, 136, 64, 128), (300, 136, 128, 128), (333, 200, 448, 128), (200, 72, 320, 64)])
 def test_gemm_deep_pipeline(backend, M, N, K, tile):
     """3-stage LDS ring variant (counted vmcnt): K of 1, 2 and many tiles"""
