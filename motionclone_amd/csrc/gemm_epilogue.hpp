@@ -71,6 +71,39 @@ struct Epilogue {
     }
     __device__ __forceinline__ void store(const GemmParams& p, const float* Cs, int m_base, int rows) {
         if (!active) return;
+        if (vec16 && p.epi == 0 && !bias_rowwise) {
+            // the common case, kept free of per-row branching: 16-byte segments, bias already in registers
+            const bool has_bias = p.bias != nullptr, has_res = p.R != nullptr;
+            half_t* crow = p.C + (size_t)(m_base + rsub) * p.ldc + n;
+            const float* srow = Cs + rsub * CS + col;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int rl = it * RPP + rsub;
+                if (rl < rows && m_base + rl < p.M) {
+                    f32x4 a = *reinterpret_cast<const f32x4*>(srow + it * RPP * CS);
+                    f32x4 b = *reinterpret_cast<const f32x4*>(srow + it * RPP * CS + 4);
+                    float v[8];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = a[e];
+                        v[4 + e] = b[e];
+                    }
+                    if (has_bias) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                    }
+                    if (has_res) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] += (float)rres[it][e];
+                    }
+                    half8_t o;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
+                    if (!(p.dbg & 1)) st8(crow + (size_t)it * RPP * p.ldc, o);
+                }
+            }
+            return;
+        }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int rl = it * RPP + rsub, m = m_base + rl;

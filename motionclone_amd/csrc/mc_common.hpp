@@ -253,11 +253,18 @@ __device__ __forceinline__ half2_t pk_rtz(float a, float b) {
 #endif
 __device__ __forceinline__ float max3(float a, float b, float c) { return fmaxf(fmaxf(a, b), c); }
 
-// saturating float -> half (fp16 max 65504); keeps NaN out of downstream tensors on overflow
+// saturating float -> half (fp16 max 65504); keeps NaN out of downstream tensors on overflow.  One v_med3_f32: the
+// fminf/fmaxf form costs an extra canonicalising v_max_f32 per value, which showed up in the GEMM epilogues.
+#ifdef MC_EMU
 __device__ inline half_t to_half(float x) {
     x = fminf(fmaxf(x, -65504.0f), 65504.0f);
     return (half_t)x;
 }
+#else
+__device__ __forceinline__ half_t to_half(float x) {
+    return (half_t)__builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f);
+}
+#endif
 
 }  // namespace mc
 
