@@ -136,6 +136,11 @@ int mc_cl_to_latent_f16(const void* in, int ld, void* out, int out_f32, float sc
 /* diffusers Timesteps(dim, flip_sin_to_cos=True, freq_shift=0) (unet.py:101,386-391) */
 int mc_timestep_embed_f16(const float* t, void* out, int B, int dim, void* stream);
 int mc_silu_f16(const void* in, void* out, long n, void* stream);
+/* VAE decode around the loop (AnimationPipeline.decode_latents, reference pipeline_animation.py:249-263; the VAE is
+ * diffusers==0.16.0 AutoencoderKL): in-place fp32 row softmax of the single-head AttentionBlock's fp16 score matrix,
+ * and the (x / 2 + 0.5).clamp(0, 1) float32 [C, F, H, W] video tail (:260-262) */
+int mc_softmax_rows_f16(void* x, int ld, int rows, int cols, void* stream);
+int mc_video_post_f32(const void* in, int ld, float* out, int C, int F, int HW, void* stream);
 /* eps = eps_c + cfg*(eps_c - eps_u) (motionclone_functions.py:239,255) followed by the guided DDIM
  * update of schedule_customized_step (:326-389, eta = 0):
  *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  eps' = eps - score_coef * score;

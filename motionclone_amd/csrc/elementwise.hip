@@ -144,6 +144,56 @@ __global__ void cl_to_latent_kernel(const half_t* in, int ld, void* out, int out
     }
 }
 
+// ---- VAE decode helpers (AutoencoderKL around the loop) ------------------------------------
+// In-place row softmax of an fp16 score matrix in fp32 (AttentionBlock: softmax(scores.float()).type(dtype)).
+// One 256-thread block per row, 16-byte vectors; three passes over a row that lives in L2.
+__global__ __launch_bounds__(256) void softmax_rows_kernel(half_t* x, int ld, int cols) {
+    __shared__ float red[8];
+    half_t* row = x + (size_t)blockIdx.x * ld;
+    const int nv = cols / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < nv; v += 256) {
+        half8_t h = ld8(row + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, (float)h[e]);
+    }
+    mx = wave_max(mx);
+    if (lane == 0) red[wave] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    float sum = 0.f;
+    for (int v = threadIdx.x; v < nv; v += 256) {
+        half8_t h = ld8(row + v * 8);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += expf((float)h[e] - mx);
+    }
+    sum = wave_sum(sum);
+    if (lane == 0) red[4 + wave] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[4] + red[5] + red[6] + red[7]);
+    for (int v = threadIdx.x; v < nv; v += 256) {
+        half8_t h = ld8(row + v * 8), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (half_t)(expf((float)h[e] - mx) * inv);
+        st8(row + v * 8, o);
+    }
+}
+
+// decode_latents tail (pipeline_animation.py:260-262): channels-last frames -> [C, F, H, W] fp32, (x / 2 + 0.5).clamp(0, 1)
+__global__ void video_post_kernel(const half_t* in, int ld, float* out, int C, int F, int HW) {
+    const long total = (long)C * F * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int p = (int)(idx % HW);
+        long r = idx / HW;
+        int f = (int)(r % F);
+        int c = (int)(r / F);
+        float v = (float)in[((size_t)f * HW + p) * ld + c] * 0.5f + 0.5f;
+        out[idx] = fminf(fmaxf(v, 0.f), 1.f);
+    }
+}
+
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ void timestep_embed_kernel(const float* t, half_t* out, int B, int dim) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,3 +328,16 @@ extern "C" int mc_cfg_ddim_step_f16(const void* eps_c, const void* eps_u, int ld
 }
 
 extern "C" int mc_version(void) { return 1; }
+
+extern "C" int mc_softmax_rows_f16(void* x, int ld, int rows, int cols, void* stream) {
+    if (rows <= 0 || cols <= 0 || cols % 8 || ld % 8 || ld < cols) return MC_ERR_SHAPE;
+    MC_LAUNCH(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, ld, cols);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_video_post_f32(const void* in, int ld, float* out, int C, int F, int HW, void* stream) {
+    if (C <= 0 || F <= 0 || HW <= 0 || ld < C) return MC_ERR_SHAPE;
+    MC_LAUNCH(video_post_kernel, dim3(ew_blocks((long)C * F * HW)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)in, ld, out, C, F, HW);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}

@@ -287,6 +287,20 @@ def cl_to_latent(x, B, CL, F, H, W, scale=1.0, f32=False):
     return out
 
 
+def softmax_rows_(x):
+    """in-place softmax over the last dim of an fp16 [rows, cols] matrix (fp32 arithmetic)"""
+    _f16(x)
+    lib.call("mc_softmax_rows_f16", _p(x), _ld(x), x.shape[0], x.shape[1], _stream(x))
+    return x
+
+
+def video_post(tokens, C, F, H, W):
+    """channels-last decoded frames [(f y x), ld] -> float32 [1, C, F, H, W], (x / 2 + 0.5).clamp(0, 1)"""
+    out = empty((1, C, F, H, W), tokens, torch.float32)
+    lib.call("mc_video_post_f32", _p(tokens), _ld(tokens), _p(out), C, F, H * W, _stream(tokens))
+    return out
+
+
 def timestep_embed(t, dim, like):
     out = empty((t.shape[0], dim), like)
     lib.call("mc_timestep_embed_f16", _p(_f32(t)), _p(out), t.shape[0], dim, _stream(like))

@@ -75,6 +75,9 @@ class AnimationPipeline:
     def decode_latents(self, latents):
         """reference :249-263: frame-wise VAE decode -> float32 numpy [B, 3, F, H, W] in [0, 1]"""
         video_length = latents.shape[2]
+        if hasattr(self.vae, "decode_video") and latents.shape[0] == 1:
+            # native AutoencoderKL: frames batched, 1/0.18215 and the (x/2+0.5).clamp(0,1) tail fused into the HIP path
+            return self.vae.decode_video(latents).cpu().float().numpy()
         latents = 1 / 0.18215 * latents
         B = latents.shape[0]
         frames = latents.permute(0, 2, 1, 3, 4).reshape(B * video_length, *latents.shape[1:2], *latents.shape[3:])
