@@ -41,7 +41,10 @@ int mc_version(void);
  * K = ctot (dense) or 9*ctot (conv; k = (c/64)*576 + tap*64 + c%64: channel-tile major, tap minor).
  * K, ctot, c1 multiples of 64; N, ldc multiples of 4.
  * flags: bits 0-7 block tile edge (0 = auto, 64, 128); 0x100 = force the first-generation kernel;
- *        0x200 = fused GEGLU epilogue: W rows interleaved (h_j, gate_j), C gets N/2 columns h_j * gelu(gate_j). */
+ *        0x200 = fused GEGLU epilogue: W rows interleaved (h_j, gate_j), C gets N/2 columns h_j * gelu(gate_j);
+ *        0x400 = 3-stage staging ring (128/64 tiles); 0x800 = mode 2 with padding only right / bottom
+ *        (diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + stride-2 conv, the VAE encoder);
+ *        bits 12-15 = large-tile geometry of gemm3.hip (0 = automatic). */
 int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
@@ -141,6 +144,9 @@ int mc_silu_f16(const void* in, void* out, long n, void* stream);
  * and the (x / 2 + 0.5).clamp(0, 1) float32 [C, F, H, W] video tail (:260-262) */
 int mc_softmax_rows_f16(void* x, int ld, int rows, int cols, void* stream);
 int mc_video_post_f32(const void* in, int ld, float* out, int C, int F, int HW, void* stream);
+/* latent_dist.sample() / .mode() of AutoencoderKL.encode (motionclone_functions.py:64,125): moment tokens
+ * [(f p), 2*LAT] (mean | logvar) and an optional standard-normal draw [n, LAT, HW] -> [n, LAT, HW] */
+int mc_vae_sample_f16(const void* moments, int ld, const void* noise, void* out, int n, int LAT, int HW, void* stream);
 /* eps = eps_c + cfg*(eps_c - eps_u) (motionclone_functions.py:239,255) followed by the guided DDIM
  * update of schedule_customized_step (:326-389, eta = 0):
  *   x0 = (x - sqrt(1-a_t) eps) / sqrt(a_t);  eps' = eps - score_coef * score;

@@ -194,6 +194,26 @@ __global__ void video_post_kernel(const half_t* in, int ld, float* out, int C, i
     }
 }
 
+// DiagonalGaussianDistribution.sample / .mode (diffusers 0.16.0 models/vae.py) from the quant_conv moment tokens
+// [(f p), 2*LAT] = (mean | logvar): out[f][c][p] = mean + exp(0.5 * clamp(logvar, -30, 20)) * noise[f][c][p]
+__global__ void vae_sample_kernel(const half_t* mom, int ld, const half_t* noise, half_t* out, int n, int LAT, int HW) {
+    const long total = (long)n * LAT * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int p = (int)(idx % HW);
+        long r = idx / HW;
+        int c = (int)(r % LAT);
+        int f = (int)(r / LAT);
+        const half_t* t = mom + ((size_t)f * HW + p) * ld;
+        float v = (float)t[c];
+        if (noise) {
+            float lv = fminf(fmaxf((float)t[LAT + c], -30.f), 20.f);
+            v += expf(0.5f * lv) * (float)noise[idx];
+        }
+        out[idx] = to_half(v);
+    }
+}
+
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ void timestep_embed_kernel(const float* t, half_t* out, int B, int dim) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -339,5 +359,13 @@ extern "C" int mc_video_post_f32(const void* in, int ld, float* out, int C, int 
     if (C <= 0 || F <= 0 || HW <= 0 || ld < C) return MC_ERR_SHAPE;
     MC_LAUNCH(video_post_kernel, dim3(ew_blocks((long)C * F * HW)), dim3(256), 0, (hipStream_t)stream,
               (const half_t*)in, ld, out, C, F, HW);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_vae_sample_f16(const void* moments, int ld, const void* noise, void* out, int n, int LAT, int HW,
+                                 void* stream) {
+    if (n <= 0 || LAT <= 0 || HW <= 0 || ld < 2 * LAT) return MC_ERR_SHAPE;
+    MC_LAUNCH(vae_sample_kernel, dim3(ew_blocks((long)n * LAT * HW)), dim3(256), 0, (hipStream_t)stream,
+              (const half_t*)moments, ld, (const half_t*)noise, (half_t*)out, n, LAT, HW);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }

@@ -105,8 +105,8 @@ __global__ __launch_bounds__(256) void gemm_kernel(GemmParams p) {
                     ix = a_ox[i] + kx - 1;
                     ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
                 } else if (MODE == CONV_S2) {
-                    iy = 2 * a_oy[i] + ky - 1;
-                    ix = 2 * a_ox[i] + kx - 1;
+                    iy = 2 * a_oy[i] + ky - p.s2_pad;
+                    ix = 2 * a_ox[i] + kx - p.s2_pad;
                     ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
                 } else if (MODE == CONV_UP) {
                     int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;  // on the upsampled grid
@@ -264,6 +264,7 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
     p.dbg = dbg_env;
     p.ws = nullptr;
     p.splits = 1;
+    p.s2_pad = (flags & 0x800) ? 0 : 1;
     int small_tile = tile == 64;
     if (tile == 0) {
         // heuristic: fall to 64x64 tiles when 128x128 would leave most of the 256 CUs idle
@@ -377,6 +378,7 @@ extern "C" int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, 
     p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
     p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = 0; p.dbg = 0;
     p.ws = ws; p.splits = splits;
+    p.s2_pad = (flags & 0x800) ? 0 : 1;
     hipStream_t s = (hipStream_t)stream;
     size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
     int rc = gemm3_dispatch(p, mode, cfg, rowsA, s);

@@ -97,8 +97,8 @@ __global__ __launch_bounds__(256) void gemm2_kernel(GemmParams p, uint32_t bytes
                     ix = a_ox[i] + kx - 1;
                     ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
                 } else if (MODE == CONV_S2) {
-                    iy = 2 * a_oy[i] + ky - 1;
-                    ix = 2 * a_ox[i] + kx - 1;
+                    iy = 2 * a_oy[i] + ky - p.s2_pad;
+                    ix = 2 * a_ox[i] + kx - p.s2_pad;
                     ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
                 } else if (MODE == CONV_UP) {
                     int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;

@@ -122,8 +122,8 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm3_kernel(GemmParams p
                     ix = a_ox[i] + kx - 1;
                     ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
                 } else if (MODE == CONV_S2) {
-                    iy = 2 * a_oy[i] + ky - 1;
-                    ix = 2 * a_ox[i] + kx - 1;
+                    iy = 2 * a_oy[i] + ky - p.s2_pad;
+                    ix = 2 * a_ox[i] + kx - p.s2_pad;
                     ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
                 } else if (MODE == CONV_UP) {
                     int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;

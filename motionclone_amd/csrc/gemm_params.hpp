@@ -24,6 +24,8 @@ struct GemmParams {
     int rows_per_batch;
     float alpha;
     int epi;    // 0: bias/residual epilogue, 1: fused GEGLU (v2 kernel only)
+    int s2_pad; // CONV_S2: zero rows / columns in front of the image: 1 (symmetric padding 1, the UNet) or 0 (pad only
+                // right / bottom: diffusers Downsample2D(padding=0) = F.pad(x, (0, 1, 0, 1)) + stride-2 conv, the VAE encoder)
     float* ws;  // split-K: fp32 partial sums [splits][M][N] (then C/R/bias are applied by the reduce kernel); else null
     int splits; // number of K ranges (grid.y); 1 without split-K
     int dbg;    // timing experiments only (MC_GEMM_DEBUG): 1 = no global stores, 2 = no k-loop, 4 = no epilogue

@@ -8,8 +8,8 @@ surface as far as the reference touches it: `from_pretrained(path, subfolder="va
 `load_state_dict()` under the 0.16.0 key names, `decode(z, return_dict=True)` returning an object with `.sample`
 in [N, 3, H, W].  `decode_video` is the batched path `decode_latents` uses when it finds it.
 
-Encoder parameters are carried (so real checkpoints load strictly) but `encode` is not on this round's path
-(next) and raises.
+`encode(x).latent_dist.sample()` (motionclone_functions.py:64,125) runs the HIP encoder engine the same way; the normal
+draw of the posterior comes from torch's (global) generator exactly where the reference draws it.
 """
 import json
 import os
@@ -18,13 +18,18 @@ from dataclasses import dataclass
 import torch
 from torch import nn
 
-from ..vae_engine import SD15_VAE_CONFIG, VaeDecoderEngine
+from ..vae_engine import SD15_VAE_CONFIG, VaeDecoderEngine, VaeEncoderEngine
 from .unet import FrozenConfig, ParamNode
 
 
 @dataclass
 class DecoderOutput:
     sample: torch.Tensor
+
+
+@dataclass
+class AutoencoderKLOutput:
+    latent_dist: object
 
 
 def _resnet_shapes(p, cin, cout):
@@ -111,6 +116,8 @@ class AutoencoderKL(nn.Module):
             node.register_parameter(parts[-1], nn.Parameter(torch.empty(shape, dtype=torch.float16), requires_grad=False))
         self._engine = None
         self._engine_key = None
+        self._enc = None
+        self._enc_key = None
 
     @property
     def dtype(self):
@@ -138,7 +145,7 @@ class AutoencoderKL(nn.Module):
 
     def load_state_dict(self, state_dict, strict=True, **kw):
         out = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._engine = None
+        self._engine = self._enc = None
         return out
 
     def engine(self):
@@ -158,9 +165,18 @@ class AutoencoderKL(nn.Module):
         """[1, 4, F, h, w] -> float32 [1, 3, F, H, W] in [0, 1]: decode_latents without the per-frame loop"""
         return self.engine().decode_video(latents)
 
+    def encoder_engine(self):
+        p0 = next(self.parameters())
+        key = (p0.device, p0.data_ptr())
+        if self._enc is None or self._enc_key != key:
+            sd = {k: v for k, v in self.state_dict().items() if k.startswith("encoder.") or k.startswith("quant_conv.")}
+            self._enc = VaeEncoderEngine(sd, self.engine_config, p0.device)
+            self._enc_key = key
+        return self._enc
+
     def encode(self, x, return_dict=True):
-        raise NotImplementedError("the VAE encoder is not on this round's HIP path (SURVEY.md 8(f)); encode the "
-                                  "reference video with the stock VAE and pass the latents in")
+        dist = self.encoder_engine().encode(x)
+        return AutoencoderKLOutput(latent_dist=dist) if return_dict else (dist,)
 
     def forward(self, *a, **k):
         raise NotImplementedError("call decode(); the training-style forward is not part of the sampling path")

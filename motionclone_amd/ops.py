@@ -47,12 +47,14 @@ def empty(shape, like, dtype=torch.float16):
 
 # ---- GEMM family ---------------------------------------------------------------------------------
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
-         rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0, splits=None):
+         rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0, splits=None,
+         pad_front=True):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
 
     geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
     geglu=True: w rows interleaved (h_j, gate_j) (see `interleave_geglu`), out gets N/2 columns h*gelu(gate).
-    splits: K ranges for the split-K path (None = the library's plan, 1 = off)."""
+    splits: K ranges for the split-K path (None = the library's plan, 1 = off).
+    pad_front=False (CONV_S2 only): zero padding only right / bottom, i.e. F.pad(x, (0, 1, 0, 1)) + stride-2 conv."""
     _f16(a), _f16(w)
     N, K = w.shape
     c1 = a.shape[1]
@@ -69,7 +71,8 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
     if out is None:
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
-    flags = tile | (0x100 if v1 else 0) | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12)
+    flags = tile | (0x100 if v1 else 0) | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
+        | (0 if pad_front else 0x800)
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N
@@ -298,6 +301,23 @@ def video_post(tokens, C, F, H, W):
     """channels-last decoded frames [(f y x), ld] -> float32 [1, C, F, H, W], (x / 2 + 0.5).clamp(0, 1)"""
     out = empty((1, C, F, H, W), tokens, torch.float32)
     lib.call("mc_video_post_f32", _p(tokens), _ld(tokens), _p(out), C, F, H * W, _stream(tokens))
+    return out
+
+
+def vae_sample(moments, noise, lat):
+    """moment tokens [(n h w), 2*lat] + N(0,1) draw [n, lat, h, w] -> mean + std * noise  [n, lat, h, w]"""
+    _f16(moments)
+    n, _, h, w = noise.shape
+    noise = _f16(noise).contiguous()
+    out = torch.empty_like(noise)
+    lib.call("mc_vae_sample_f16", _p(moments), _ld(moments), _p(noise), _p(out), n, lat, h * w, _stream(moments))
+    return out
+
+
+def vae_mode(moments, n, lat, h, w):
+    _f16(moments)
+    out = empty((n, lat, h, w), moments)
+    lib.call("mc_vae_sample_f16", _p(moments), _ld(moments), None, _p(out), n, lat, h * w, _stream(moments))
     return out
 
 

@@ -84,8 +84,32 @@ def test_autoencoderkl_dropin_and_pipeline(backend, tiny_vae):
         want = V.decode_latents(sd, cfg, lat.float().cpu()).numpy()
     assert isinstance(video, np.ndarray) and video.dtype == np.float32 and video.shape == (1, 3, 2, 16, 16)
     assert np.abs(video - want).max() < 2e-2
-    with pytest.raises(NotImplementedError):
-        vae.encode(torch.zeros(1, 3, 16, 16))
+    # encode side (motionclone_functions.py:64-65): latent_dist.sample() * scaling_factor, noise from torch's generator
+    img = (torch.rand(2, 3, 16, 16, generator=torch.Generator().manual_seed(8)) * 2 - 1).half()
+    dist = vae.encode(img.to(dev)).latent_dist
+    gen = torch.Generator(device=dev).manual_seed(123)
+    smp = dist.sample(gen)
+    noise = torch.randn((2, 4, 8, 8), generator=torch.Generator(device=dev).manual_seed(123), device=dev, dtype=torch.float16)
+    with torch.no_grad():
+        want = V.encode_sample(sd, cfg, img.float(), noise.float().cpu())
+        mean, _ = V.encode_moments(sd, cfg, img.float())
+    assert smp.shape == (2, 4, 8, 8) and rel(smp, want) < 2e-2
+    assert rel(dist.mode(), mean) < 2e-2
+
+
+def test_encoder_matches_oracle(backend, tiny_vae):
+    dev = backend
+    cfg, sd = tiny_vae
+    from motionclone_amd.vae_engine import VaeEncoderEngine
+    eng = VaeEncoderEngine(sd, cfg, dev)
+    img = (torch.rand(3, 3, 16, 16, generator=torch.Generator().manual_seed(4)) * 2 - 1).half()
+    dist = eng.encode(img.to(dev))
+    with torch.no_grad():
+        mean, std = V.encode_moments(sd, cfg, img.float())
+    assert rel(dist.mode(), mean) < 2e-2, rel(dist.mode(), mean)
+    noise = torch.ones(3, 4, 8, 8, dtype=torch.float16)
+    one = ops.vae_sample(dist._tok, noise.to(dev), 4)
+    assert rel(one.float().cpu() - dist.mode().float().cpu(), std) < 3e-2     # mean + std * 1
 
 
 @pytest.mark.gpu
@@ -113,3 +137,12 @@ def test_full_size_decoder_one_frame_vs_oracle():
     assert torch.isfinite(v1).all() and float(v1.min()) >= 0 and float(v1.max()) <= 1
     single = eng.decode_video(lat[:, :, 5:6])
     assert (single[0, :, 0] - v1[0, :, 5]).abs().max() < 5e-3
+    # encoder: 2 frames of 256x256 against the oracle
+    from motionclone_amd.vae_engine import VaeEncoderEngine
+    sde = {k: v.half().float() for k, v in V.random_state_dict(cfg, seed=4242).items() if k.startswith("encoder") or k.startswith("quant")}
+    enc = VaeEncoderEngine(sde, cfg, dev)
+    img = (torch.rand(2, 3, 256, 256, generator=torch.Generator().manual_seed(4)) * 2 - 1).half()
+    dist = enc.encode(img.to(dev))
+    with torch.no_grad():
+        mean, std = V.encode_moments(sde, cfg, img.float())
+    assert rel(dist.mode(), mean) < 2e-2, rel(dist.mode(), mean)
