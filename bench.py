@@ -122,6 +122,44 @@ def one_video(smp, lat, text, vid, noise, step_events=None, ctrl=None):
     return x
 
 
+def vae_extras(dev, latents_tokens_or_lat, frames, size):
+    """decode_latents (pipeline_animation.py:249-263) and vae.encode of the reference frames (motionclone_functions.py:64)
+    on synthetic SD-1.5 AutoencoderKL weights, HIP path; seconds per video, median of 3."""
+    from motionclone_amd.models.vae import vae_param_shapes
+    from motionclone_amd.vae_engine import SD15_VAE_CONFIG, VaeDecoderEngine, VaeEncoderEngine
+    g = torch.Generator(device=dev).manual_seed(4242)
+    sd = {}
+    for name, shape in vae_param_shapes(SD15_VAE_CONFIG).items():
+        fan = 1
+        for d in shape[1:]:
+            fan *= d
+        if "norm" in name:
+            sd[name] = (1.0 if name.endswith("weight") else 0.0) + 0.1 * torch.randn(shape, generator=g, device=dev)
+        elif name.endswith("bias"):
+            sd[name] = 0.02 * torch.randn(shape, generator=g, device=dev)
+        else:
+            sd[name] = (torch.rand(shape, generator=g, device=dev) * 2 - 1) / fan ** 0.5
+    dec = VaeDecoderEngine({k: v for k, v in sd.items() if k.startswith(("decoder.", "post_quant"))}, None, dev)
+    enc = VaeEncoderEngine({k: v for k, v in sd.items() if k.startswith(("encoder.", "quant_conv"))}, None, dev)
+    lat = (0.18215 * torch.randn((1, 4, frames, size // 8, size // 8), generator=g, device=dev)).half()
+    img = (torch.rand((frames, 3, size, size), generator=g, device=dev) * 2 - 1).half()
+
+    def med(fn):
+        fn()
+        ts = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts.append(time.perf_counter() - t0)
+        return sorted(ts)[1]
+    d = med(lambda: dec.decode_video(lat))
+    e = med(lambda: enc.encode(img).sample())
+    return dict(decode_sec_per_video=d, encode_sec_per_video=e, frames=frames, size=size,
+                note="diffusers 0.16.0 AutoencoderKL architecture, synthetic weights; not part of `value`")
+
+
 def cpu_baseline():
     """The oracle (CPU restatement of the reference path, oracle/unet3d_ref.py) timed on this box's host cores on a
     bounded sample: one B=1 fp32 UNet3D forward of the full SD1.5+AnimateDiff architecture at 16f x 256x256, its
@@ -167,6 +205,7 @@ def main():
     ap.add_argument("--guided-steps", type=int, default=18)
     ap.add_argument("--guidance-scale", type=float, default=0.4)
     ap.add_argument("--sparsectrl", action="store_true", help="BASELINE config 4: add the SparseCtrl (i2v_rgb) encoder pass")
+    ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -239,6 +278,9 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
+    vae_info = None
+    if rank == 0 and not args.no_vae:
+        vae_info = vae_extras(dev, out, args.frames, args.size)
     if rank == 0:
         gsec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if g]
         psec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if not g]
@@ -282,6 +324,9 @@ def main():
             "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
             "roofline": roof,
             "roofline_by_kernel": roof_all,
+            # SURVEY.md 8(f) rank 1, measured OUTSIDE the timed region (BASELINE's metric is the UNet loop): the VAE calls
+            # around it - decode_latents of the sampled video and the encode of the reference video - on the same kernels
+            "vae": vae_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline()
