@@ -22,19 +22,62 @@ def set_all_seed(seed):
     random.seed(seed)
 
 
-def load_weights(pipeline, motion_module_path="", dreambooth_model_path="", **unused):
-    """reference util.py:115-215.  Loads an AnimateDiff motion-module checkpoint (keys containing
-    'motion_modules.') into the UNet; DreamBooth / LoRA conversion needs the LDM->diffusers key maps, which are
-    load-time host code outside the hot path."""
-    if motion_module_path:
-        sd = torch.load(motion_module_path, map_location="cpu")
-        sd = sd["state_dict"] if "state_dict" in sd else sd
+def _load_checkpoint_file(path):
+    if path.endswith(".safetensors"):
+        from safetensors import safe_open
+        sd = {}
+        with safe_open(path, framework="pt", device="cpu") as f:
+            for key in f.keys():
+                sd[key] = f.get_tensor(key)
+        return sd
+    return torch.load(path, map_location="cpu")
+
+
+def _unwrap(sd):
+    sd = sd["state_dict"] if "state_dict" in sd else sd
+    sd.pop("animatediff_config", "")
+    return sd
+
+
+def load_weights(animation_pipeline, motion_module_path="", motion_module_lora_configs=(), adapter_lora_path="",
+                 adapter_lora_scale=1.0, dreambooth_model_path="", lora_model_path="", lora_alpha=0.8):
+    """reference util.py:115-215, same argument names and order of operations: motion module -> DreamBooth / base
+    checkpoint in the original Stable-Diffusion layout (VAE, UNet, text encoder) -> kohya LoRA -> domain-adapter LoRA ->
+    motion LoRAs.  The key maps and merges live in utils/convert.py; after any of them the packed HIP weights are
+    rebuilt on next use."""
+    from .convert import (convert_ldm_clip_checkpoint_concise, convert_ldm_unet_checkpoint, convert_ldm_vae_checkpoint,
+                          convert_lora, load_diffusers_lora)
+    pipeline = animation_pipeline
+    if motion_module_path != "":
+        print(f"load motion module from {motion_module_path}")
+        sd = _unwrap(torch.load(motion_module_path, map_location="cpu"))
         sd = {k: v for k, v in sd.items() if "motion_modules." in k and "pos_encoder.pe" not in k}
         missing, unexpected = pipeline.unet.load_state_dict(sd, strict=False)
         assert len(unexpected) == 0, unexpected
-        print(f"load motion module from {motion_module_path}")
-    if dreambooth_model_path:
-        raise NotImplementedError("DreamBooth/LoRA checkpoint conversion is not part of the hot path (SURVEY.md 8f)")
+    if dreambooth_model_path != "":
+        print(f"load dreambooth model from {dreambooth_model_path}")
+        ckpt = _load_checkpoint_file(dreambooth_model_path)
+        ckpt = ckpt["state_dict"] if "state_dict" in ckpt else ckpt
+        pipeline.vae.load_state_dict(convert_ldm_vae_checkpoint(ckpt, pipeline.vae.config))
+        pipeline.unet.load_state_dict(convert_ldm_unet_checkpoint(ckpt, pipeline.unet.config), strict=False)
+        if getattr(pipeline, "text_encoder", None) is not None:
+            te = convert_ldm_clip_checkpoint_concise(ckpt)
+            own = pipeline.text_encoder.state_dict()
+            # newer transformers no longer register position_ids as a persistent buffer; everything else must match
+            te = {k: v for k, v in te.items() if k in own or not k.endswith("position_ids")}
+            pipeline.text_encoder.load_state_dict(te, strict=True)
+    if lora_model_path != "":
+        print(f"load lora model from {lora_model_path}")
+        assert lora_model_path.endswith(".safetensors")
+        pipeline = convert_lora(pipeline, _load_checkpoint_file(lora_model_path), alpha=lora_alpha)
+    if adapter_lora_path != "":
+        print(f"load domain lora from {adapter_lora_path}")
+        pipeline = load_diffusers_lora(pipeline, _unwrap(torch.load(adapter_lora_path, map_location="cpu")),
+                                       alpha=adapter_lora_scale)
+    for cfg in motion_module_lora_configs:
+        path, alpha = cfg["path"], cfg["alpha"]
+        print(f"load motion LoRA from {path}")
+        pipeline = load_diffusers_lora(pipeline, _unwrap(torch.load(path, map_location="cpu")), alpha)
     return pipeline
 
 
