@@ -144,6 +144,9 @@ int mc_silu_f16(const void* in, void* out, long n, void* stream);
  * and the (x / 2 + 0.5).clamp(0, 1) float32 [C, F, H, W] video tail (:260-262) */
 int mc_softmax_rows_f16(void* x, int ld, int rows, int cols, void* stream);
 int mc_video_post_f32(const void* in, int ld, float* out, int C, int F, int HW, void* stream);
+/* reference-video front end behind the decoder (util.py:232-238): uint8 frames [N, Hs, Ws, 3] -> bilinear
+ * (align_corners=True) -> [N, 3, H, W] fp16 in [-1, 1]; quantise != 0 re-rounds to 0..255 like the reference's uint8 resize */
+int mc_video_resize_u8_f16(const void* in, void* out, int N, int Hs, int Ws, int H, int W, int quantise, void* stream);
 /* latent_dist.sample() / .mode() of AutoencoderKL.encode (motionclone_functions.py:64,125): moment tokens
  * [(f p), 2*LAT] (mean | logvar) and an optional standard-normal draw [n, LAT, HW] -> [n, LAT, HW] */
 int mc_vae_sample_f16(const void* moments, int ld, const void* noise, void* out, int n, int LAT, int HW, void* stream);

@@ -214,6 +214,35 @@ __global__ void vae_sample_kernel(const half_t* mom, int ld, const half_t* noise
     }
 }
 
+// Reference-video front end after the decoder (reference motionclone/utils/util.py:232-238): frames uint8 [N, Hs, Ws, 3]
+// (decord layout) -> bilinear resize with align_corners=True -> / 127.5 - 1 -> fp16 [N, 3, H, W].  The reference
+// interpolates the uint8 tensor, i.e. the resized value is re-quantised to 0..255 before normalisation; here it is
+// rounded to nearest (torch's uint8 path is fixed-point and differs from that by at most one level).
+__global__ void video_resize_kernel(const uint8_t* in, half_t* out, int N, int Hs, int Ws, int H, int W, int quantise) {
+    const long total = (long)N * 3 * H * W;
+    const float sy = H > 1 ? (float)(Hs - 1) / (float)(H - 1) : 0.f;
+    const float sx = W > 1 ? (float)(Ws - 1) / (float)(W - 1) : 0.f;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int x = (int)(idx % W);
+        long r = idx / W;
+        int y = (int)(r % H);
+        r /= H;
+        int c = (int)(r % 3);
+        int n = (int)(r / 3);
+        float fy = sy * y, fx = sx * x;
+        int y0 = (int)fy, x0 = (int)fx;
+        int y1 = min(y0 + 1, Hs - 1), x1 = min(x0 + 1, Ws - 1);
+        float wy = fy - y0, wx = fx - x0;
+        const uint8_t* f = in + (size_t)n * Hs * Ws * 3;
+        float v00 = f[((size_t)y0 * Ws + x0) * 3 + c], v01 = f[((size_t)y0 * Ws + x1) * 3 + c];
+        float v10 = f[((size_t)y1 * Ws + x0) * 3 + c], v11 = f[((size_t)y1 * Ws + x1) * 3 + c];
+        float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
+        if (quantise) v = rintf(v);
+        out[idx] = (half_t)(v / 127.5f - 1.0f);
+    }
+}
+
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ void timestep_embed_kernel(const float* t, half_t* out, int B, int dim) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -367,5 +396,13 @@ extern "C" int mc_vae_sample_f16(const void* moments, int ld, const void* noise,
     if (n <= 0 || LAT <= 0 || HW <= 0 || ld < 2 * LAT) return MC_ERR_SHAPE;
     MC_LAUNCH(vae_sample_kernel, dim3(ew_blocks((long)n * LAT * HW)), dim3(256), 0, (hipStream_t)stream,
               (const half_t*)moments, ld, (const half_t*)noise, (half_t*)out, n, LAT, HW);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_video_resize_u8_f16(const void* in, void* out, int N, int Hs, int Ws, int H, int W, int quantise,
+                                      void* stream) {
+    if (N <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return MC_ERR_SHAPE;
+    MC_LAUNCH(video_resize_kernel, dim3(ew_blocks((long)N * 3 * H * W)), dim3(256), 0, (hipStream_t)stream,
+              (const uint8_t*)in, (half_t*)out, N, Hs, Ws, H, W, quantise);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }

@@ -24,6 +24,7 @@ SIGNATURES = {
     "mc_softmax_rows_f16": [P, I, I, I, P],
     "mc_video_post_f32": [P, I, P, I, I, I, P],
     "mc_vae_sample_f16": [P, I, P, P, I, I, I, P],
+    "mc_video_resize_u8_f16": [P, P, I, I, I, I, I, I, P],
     "mc_gemm_splitk_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P, I, P],
     "mc_gn_nchunk": [I],
     "mc_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, F, P, P, P],

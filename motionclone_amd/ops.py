@@ -304,6 +304,16 @@ def video_post(tokens, C, F, H, W):
     return out
 
 
+def video_resize(frames_u8, H, W, quantise=True):
+    """uint8 [N, Hs, Ws, 3] (device) -> fp16 [N, 3, H, W] in [-1, 1]: bilinear align_corners=True, / 127.5 - 1"""
+    assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3
+    frames_u8 = frames_u8.contiguous()
+    N, Hs, Ws, _ = frames_u8.shape
+    out = torch.empty((N, 3, H, W), dtype=torch.float16, device=frames_u8.device)
+    lib.call("mc_video_resize_u8_f16", _p(frames_u8), _p(out), N, Hs, Ws, H, W, int(quantise), _stream(frames_u8))
+    return out
+
+
 def vae_sample(moments, noise, lat):
     """moment tokens [(n h w), 2*lat] + N(0,1) draw [n, lat, h, w] -> mean + std * noise  [n, lat, h, w]"""
     _f16(moments)

@@ -81,18 +81,34 @@ def load_weights(animation_pipeline, motion_module_path="", motion_module_lora_c
     return pipeline
 
 
-def video_preprocess(video_path, height, width, video_length, duration=None, sample_start_idx=0):
+def pick_frames(n_total, video_length, fps=None, duration=None):
+    """frame indices of util.py:222-230: the first `duration` seconds (or everything), `video_length` evenly spaced picks"""
+    total = n_total if duration is None else min(int(fps * duration), n_total)
+    return np.linspace(0, total - 1, video_length, dtype=int)
+
+
+def preprocess_frames(frames_u8, height, width, device=None):
+    """util.py:232-238 behind the decoder: uint8 [F, H, W, 3] (numpy or tensor) -> [F, 3, height, width] in [-1, 1];
+    resize + normalise are one HIP kernel (`mc_video_resize_u8_f16`)"""
+    from .. import ops
+    t = torch.as_tensor(frames_u8)
+    if device is not None:
+        t = t.to(device)
+    return ops.video_resize(t, height, width)
+
+
+def video_preprocess(video_path, height, width, video_length, duration=None, sample_start_idx=0, device=None):
     """reference util.py:217-242: decode -> np.linspace frame pick -> bilinear resize(align_corners=True) -> [-1, 1].
-    Needs decord, which is not part of this image; synthetic latents bypass it."""
+    The decoder is `decord` as in the reference (not part of this image: pass frames to `preprocess_frames`, or video
+    latents straight to `obtain_motion_representation(video_latents=...)`)."""
     try:
-        import decord  # noqa: F401
+        import decord
     except ImportError as e:
-        raise RuntimeError("video decode needs `decord`; pass video latents directly "
-                           "(obtain_motion_representation(video_latents=...))") from e
+        raise RuntimeError("video decode needs `decord`; pass decoded frames to preprocess_frames() or video latents "
+                           "directly (obtain_motion_representation(video_latents=...))") from e
     vr = decord.VideoReader(video_path)
-    fps = vr.get_avg_fps()
-    total = len(vr) if duration is None else min(int(duration * fps), len(vr))
-    idx = np.linspace(sample_start_idx, total - 1, video_length, dtype=int)
-    frames = torch.from_numpy(vr.get_batch(idx).asnumpy()).permute(0, 3, 1, 2).float()
-    frames = torch.nn.functional.interpolate(frames, size=(height, width), mode="bilinear", align_corners=True)
-    return frames / 127.5 - 1.0
+    idx = pick_frames(len(vr), video_length, vr.get_avg_fps(), duration)
+    frames = vr.get_batch(idx)
+    frames = frames.asnumpy() if hasattr(frames, "asnumpy") else frames
+    dev = device if device is not None else ("cuda" if torch.cuda.is_available() else None)
+    return preprocess_frames(frames, height, width, device=dev)

@@ -416,3 +416,24 @@ def test_cfg_ddim_step(backend):
     close(out, ref, 2e-2, 3e-3, "cfg+ddim guided")
     out2 = ops.cfg_ddim_step(ec_cl, eu_cl, x, None, cfg, a_t, a_prev, 0.0)
     close(out2, math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps, 2e-2, 3e-3, "cfg+ddim plain")
+
+
+def test_video_resize(backend):
+    """reference-video front end (util.py:232-238): bilinear align_corners resize of uint8 frames + normalisation"""
+    dev = backend
+    g = torch.Generator().manual_seed(0)
+    x = torch.randint(0, 256, (3, 37, 53, 3), generator=g, dtype=torch.uint8)
+    got = ops.video_resize(x.to(dev), 32, 48)
+    xf = x.permute(0, 3, 1, 2).float()
+    ref = Fn.interpolate(xf, size=(32, 48), mode="bilinear", align_corners=True)
+    assert got.shape == (3, 3, 32, 48) and got.dtype == torch.float16
+    want = ref.round() / 127.5 - 1.0
+    assert (got.float().cpu() - want).abs().max() < 1.01 / 127.5 + 1e-3          # at most one level at .5 ties
+    assert ((got.float().cpu() - want).abs() > 2e-3).float().mean() < 0.01
+    u8 = Fn.interpolate(x.permute(0, 3, 1, 2), size=(32, 48), mode="bilinear", align_corners=True).float() / 127.5 - 1.0
+    assert (got.float().cpu() - u8).abs().max() < 1.01 / 127.5 + 1e-3             # torch's own uint8 path: +-1 level
+    smooth = ops.video_resize(x.to(dev), 32, 48, quantise=False)
+    assert (smooth.float().cpu() - (ref / 127.5 - 1.0)).abs().max() < 2e-3
+    from motionclone_amd.utils.util import pick_frames, preprocess_frames
+    assert pick_frames(100, 4).tolist() == [0, 33, 66, 99] and pick_frames(100, 3, fps=10.0, duration=2.05).tolist() == [0, 9, 19]
+    assert torch.equal(preprocess_frames(x.numpy(), 32, 48, device=dev), got)
