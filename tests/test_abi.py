@@ -60,5 +60,5 @@ def test_product_path_fails_loudly_without_the_library(monkeypatch, tmp_path):
         lib.load()
     import torch
     from motionclone_amd import ops
-    with pytest.raises(lib.KernelLibraryMissing):
+    with pytest.raises(RuntimeError, match="no CPU fallback"):       # CPU tensors are refused outright
         ops.silu(torch.zeros(8, dtype=torch.float16))
