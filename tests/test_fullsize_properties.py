@@ -94,3 +94,19 @@ def test_guidance_gradient_is_linear_in_weight_and_step_is_consistent(full):
     x_g = ops.cfg_ddim_step(ec, eu, lat, g2, 7.5, a_t, a_prev, (1 - a_t) ** 0.5)
     want = x_plain.float() - (1 - a_prev) ** 0.5 * (1 - a_t) ** 0.5 * g2
     assert rel(x_g, want) < 2e-3
+
+
+def test_graph_replay_matches_eager(full):
+    """hipGraph capture of whole steps (sampler.enable_graphs): a guided and a plain step replayed from their graphs give
+    bit-identical latents to the eager launches, also for a latent that was not the one captured"""
+    eng, smp, lat, text, vid, noise = full
+    rep_dev = eng.prepare_representation(eng.extract_representation(smp.add_noise(400, vid, noise), 400, text[0:1]))
+    smg = MotionCloneSampler(eng, num_inference_steps=30, guidance_steps=18, guidance_scale=0.4).enable_graphs()
+    lat2 = (lat.float() * 0.9 + 0.05).half()
+    for i in (0, 25):
+        want1 = smp.step(lat, i, text, rep_dev)
+        want2 = smp.step(lat2, i, text, rep_dev)
+        got_first = smg.step(lat, i, text, rep_dev)            # eager + capture
+        got1 = smg.step(lat, i, text, rep_dev).clone()         # replay
+        got2 = smg.step(lat2, i, text, rep_dev).clone()        # replay with another latent
+        assert torch.equal(got_first, want1) and torch.equal(got1, want1) and torch.equal(got2, want2)
