@@ -486,6 +486,7 @@ class UNet3DEngine:
         return out, g2
 
     # ---- whole network --------------------------------------------------------------------------------
+    @ops.scoped
     def forward(self, latents, t, text, tape=None, record=None, seeds=None, only_motion_feature=False,
                 down_residuals=None, mid_residual=None):
         """latents [B, 4, F, H, W] fp16, text [B, n_text, xdim] fp16 -> eps as a token matrix [(b f y x), 4].
@@ -575,6 +576,7 @@ class UNet3DEngine:
         return ["up_blocks.%d.motion_modules.%d.temporal_transformer.transformer_blocks.0.attention_blocks.%d"
                 % (self.guidance_block, j, a) for j in range(L + 1) for a in range(2)]
 
+    @ops.scoped
     def extract_representation(self, noisy_latents, t, uncond_text, down_residuals=None, mid_residual=None):
         """model part of obtain_motion_representation (motionclone_functions.py:74-79): partial forward to the
         guidance block, P = softmax(scale q k^T) of the hooked temporal attentions, top-1 value/index."""
@@ -596,6 +598,7 @@ class UNet3DEngine:
             out[name] = (idx.to(self.dev, torch.uint8).contiguous(), val.to(self.dev, torch.float32).contiguous())
         return out
 
+    @ops.scoped
     def guided_eps_and_grad(self, latents, t, text_cond, rep_dev, weight, want_loss=False, down_residuals=None,
                             mid_residual=None, text_uncond=None):
         """eps_c forward with the in-graph half taped + backward of  weight * sum_m mse_m  w.r.t. the latent
@@ -651,6 +654,7 @@ class ControlNetEngine(UNet3DEngine):
             names += ["down_blocks.%d.resnets.%d." % (i, j) for j in range(L)]
         return names + ["mid_block.resnets.0.", "mid_block.resnets.1."]
 
+    @ops.scoped
     def forward(self, sample_shape, t, text, cond, mask, conditioning_scale=1.0):
         """sample_shape = (B, 4, F, H, W); cond [1, Cc, F, H, W] latent condition (zeros on unconditioned frames),
         mask [1, 1, F, H, W]; text [B, n, dim] -> (list of 12 residual token matrices [(b f y x), C], mid residual)"""

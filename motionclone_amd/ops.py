@@ -11,9 +11,30 @@ from . import lib
 DENSE, CONV_S1, CONV_S2, CONV_UP, TCONV_S2 = 0, 1, 2, 3, 4
 
 
+_STREAM = None   # HIP stream handle pinned for the duration of one engine call (see `scoped`)
+
+
+def scoped(fn):
+    """Decorator for the engine entry points: look the current HIP stream up once per call instead of once per kernel
+    launch (the lookup is ~1.8 us of the ~8 us a wrapper call costs on the host, and a step issues ~1000 launches).
+    Evaluated when the method is entered, so a call made under hipGraph capture pins the capturing stream."""
+    def wrapper(self, *a, **k):
+        global _STREAM
+        prev = _STREAM
+        dev = getattr(self, "dev", None)
+        if prev is None and dev is not None and dev.type == "cuda":
+            _STREAM = torch.cuda.current_stream(dev).cuda_stream
+        try:
+            return fn(self, *a, **k)
+        finally:
+            _STREAM = prev
+    wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
+    return wrapper
+
+
 def _stream(t):
     if t.is_cuda:
-        return torch.cuda.current_stream(t.device).cuda_stream
+        return _STREAM if _STREAM is not None else torch.cuda.current_stream(t.device).cuda_stream
     if not lib.is_emulated():
         raise RuntimeError("motionclone_amd kernels run on an MI355X; got a CPU tensor and no GPU library "
                            "(there is no CPU fallback)")

@@ -32,6 +32,7 @@ class MotionCloneSampler:
                  num_inference_steps=30, guidance_steps=18, guidance_scale=0.4, score_guidance_scale=1.0,
                  controlnet=None, batch_guided=True):
         self.engine = engine
+        self.dev = engine.dev
         # True: guided steps run eps_u / eps_c as one B = 2 forward (same per-sample arithmetic as the reference's
         # two B = 1 calls, fewer and larger launches); False: two separate forwards exactly as the reference issues them
         self.batch_guided = batch_guided
@@ -68,6 +69,7 @@ class MotionCloneSampler:
         a = float(self.acp[int(t)])
         return (a ** 0.5 * x0.float() + (1 - a) ** 0.5 * noise.float()).to(x0.dtype)
 
+    @ops.scoped
     def extract(self, video_latents, noise, uncond_text, add_noise_step=400, ctrl=None):
         """ctrl = dict(cond, mask, scale) runs the SparseCtrl encoder first (motionclone_functions.py:46-72)"""
         noisy = self.add_noise(add_noise_step, video_latents, noise)
@@ -116,6 +118,7 @@ class MotionCloneSampler:
             return self._graphed_step(latents, i, text, rep_dev, ctrl)
         return self._step_eager(latents, i, text, rep_dev, aux, ctrl)
 
+    @ops.scoped
     def _step_eager(self, latents, i, text, rep_dev, aux=None, ctrl=None):
         from .engine import split_residuals
         eng = self.engine

@@ -105,6 +105,7 @@ class VaeDecoderEngine(VaeBlocks):
         per_frame = 2.0 * (h * up) * (w * up) * max(ch[0], ch[1] if len(ch) > 1 else ch[0])
         return max(1, int(ACT_BUDGET // per_frame))
 
+    @ops.scoped
     def decode_tokens(self, z, scale=1.0):
         """z [n, latent, h, w] fp16 -> (tokens [(n H W), 4] fp16 with the first 3 columns = RGB, H, W)"""
         cfg, w = self.cfg, self.w
@@ -194,6 +195,7 @@ class VaeEncoderEngine(VaeBlocks):
         per_frame = 2.0 * H * W * self.cfg["block_out_channels"][0]
         return max(1, int(ACT_BUDGET // per_frame))
 
+    @ops.scoped
     def encode_tokens(self, x):
         """x [n, 3, H, W] fp16 in [-1, 1] -> (moment tokens [(n h w), 2 * latent], h, w)"""
         cfg, w = self.cfg, self.w
