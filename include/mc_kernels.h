@@ -92,6 +92,10 @@ int mc_layernorm_bwd_f16(const void* dy, int lddy, const void* x, int ldx, const
 int mc_attn_fwd_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o, int ldo,
                     float* lse, int Nq, int Nk, int heads, int d, int nbatch, int kv_bdiv, float scale,
                     void* stream);
+/* causal self-attention forward, N queries = N keys (the CLIP text encoder of pipeline_animation.py:160-247,
+ * transformers CLIPTextModel: key j is masked for query i when j > i); no log-sum-exp output */
+int mc_attn_fwd_causal_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o, int ldo,
+                           int N, int heads, int d, int nbatch, float scale, void* stream);
 /* dq always; dk/dv when non-NULL (requires kv_bdiv == 1).  Dbuf: float[nbatch*heads*Nq] workspace. */
 int mc_attn_bwd_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, const void* o,
                     int ldo, const void* dO, int lddo, const float* lse, float* Dbuf, void* dq, int lddq,
@@ -144,6 +148,10 @@ int mc_silu_f16(const void* in, void* out, long n, void* stream);
  * and the (x / 2 + 0.5).clamp(0, 1) float32 [C, F, H, W] video tail (:260-262) */
 int mc_softmax_rows_f16(void* x, int ld, int rows, int cols, void* stream);
 int mc_video_post_f32(const void* in, int ld, float* out, int C, int F, int HW, void* stream);
+/* CLIP text encoder pieces: token + position embedding lookup, quick_gelu (x * sigmoid(1.702 x)) */
+int mc_clip_embed_f16(const long* ids, const void* tok, const void* pos, void* out, int B, int S, int C, int vocab,
+                      void* stream);
+int mc_quick_gelu_f16(const void* in, void* out, long n, void* stream);
 /* reference-video front end behind the decoder (util.py:232-238): uint8 frames [N, Hs, Ws, 3] -> bilinear
  * (align_corners=True) -> [N, 3, H, W] fp16 in [-1, 1]; quantise != 0 re-rounds to 0..255 like the reference's uint8 resize */
 int mc_video_resize_u8_f16(const void* in, void* out, int N, int Hs, int Ws, int H, int W, int quantise, void* stream);

@@ -27,6 +27,7 @@ struct AParams {
     int ldq, ldk, ldv;
     int Nq, Nk, heads, d, nbatch, kv_bdiv;
     float scale;
+    int causal;   // forward only: key j attends to query i iff j <= i (CLIP text encoder); 0 on the UNet path
 };
 
 constexpr int KV_TILE = 64;
@@ -258,6 +259,14 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
                         if (kv0 + 16 * j + 4 * g + i >= P.Nk) st[t][j][i] = -INFINITY;
+            }
+            if (P.causal) {  // wave-uniform: the lane's query row is q0 + 16 t + c15, its keys kv0 + 16 j + 4 g + i
+                const int qrow = q0 + 16 * t + c15;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (kv0 + 16 * j + 4 * g + i > qrow) st[t][j][i] = -INFINITY;
             }
             float mx = max3(st[t][0][0], st[t][0][1], st[t][0][2]);
             mx = max3(mx, st[t][0][3], st[t][1][0]);
@@ -694,7 +703,7 @@ static AParams a_params(const void* q, const void* k, const void* v, int ldq, in
     AParams P;
     P.q = (const half_t*)q; P.k = (const half_t*)k; P.v = (const half_t*)v;
     P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.Nq = Nq; P.Nk = Nk; P.heads = heads; P.d = d;
-    P.nbatch = nbatch; P.kv_bdiv = kv_bdiv; P.scale = scale;
+    P.nbatch = nbatch; P.kv_bdiv = kv_bdiv; P.scale = scale; P.causal = 0;
     return P;
 }
 
@@ -707,6 +716,20 @@ extern "C" int mc_attn_fwd_f16(const void* q, const void* k, const void* v, int 
     int dt = (d + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
 #define CALL(DT_) a_launch_fwd<DT_>(P, (half_t*)o, ldo, lse, s)
+    MC_A_DISPATCH(CALL)
+#undef CALL
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// causal self-attention forward (CLIP text encoder): same contract, key j masked for query i when j > i
+extern "C" int mc_attn_fwd_causal_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o,
+                                      int ldo, int N, int heads, int d, int nbatch, float scale, void* stream) {
+    AParams P = a_params(q, k, v, ldq, ldk, ldv, N, N, heads, d, nbatch, 1, scale);
+    P.causal = 1;
+    if (!a_check(P) || ldo % 4) return MC_ERR_SHAPE;
+    int dt = (d + 15) / 16;
+    hipStream_t s = (hipStream_t)stream;
+#define CALL(DT_) a_launch_fwd<DT_>(P, (half_t*)o, ldo, nullptr, s)
     MC_A_DISPATCH(CALL)
 #undef CALL
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;

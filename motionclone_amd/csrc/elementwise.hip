@@ -243,6 +243,39 @@ __global__ void video_resize_kernel(const uint8_t* in, half_t* out, int N, int H
     }
 }
 
+// ---- CLIP text encoder helpers (transformers CLIPTextModel, reference pipeline_animation.py:160-247) ---------------
+// embeddings: out[(b s), :] = token_embedding[ids[b][s]] + position_embedding[s]
+__global__ void clip_embed_kernel(const long* ids, const half_t* tok, const half_t* pos, half_t* out, int B, int S, int C,
+                                  int vocab) {
+    const int nv = C / 8;
+    const long total = (long)B * S * nv;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int v = (int)(idx % nv);
+        long r = idx / nv;
+        int sidx = (int)(r % S);
+        long id = ids[r];
+        id = id < 0 ? 0 : (id >= vocab ? vocab - 1 : id);
+        half8_t a = ld8(tok + (size_t)id * C + v * 8), b = ld8(pos + (size_t)sidx * C + v * 8), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = to_half((float)a[e] + (float)b[e]);
+        st8(out + (size_t)r * C + v * 8, o);
+    }
+}
+// quick_gelu: x * sigmoid(1.702 x)
+__global__ void quick_gelu_kernel(const half_t* in, half_t* out, long n) {
+    for (long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8; idx < n;
+         idx += (long)gridDim.x * blockDim.x * 8) {
+        half8_t a = ld8(in + idx), o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float x = (float)a[e];
+            o[e] = to_half(x / (1.0f + expf(-1.702f * x)));
+        }
+        st8(out + idx, o);
+    }
+}
+
 // diffusers Timesteps(dim, flip_sin_to_cos=True, downscale_freq_shift=0): [cos | sin]
 __global__ void timestep_embed_kernel(const float* t, half_t* out, int B, int dim) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -404,5 +437,20 @@ extern "C" int mc_video_resize_u8_f16(const void* in, void* out, int N, int Hs, 
     if (N <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return MC_ERR_SHAPE;
     MC_LAUNCH(video_resize_kernel, dim3(ew_blocks((long)N * 3 * H * W)), dim3(256), 0, (hipStream_t)stream,
               (const uint8_t*)in, (half_t*)out, N, Hs, Ws, H, W, quantise);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_clip_embed_f16(const long* ids, const void* tok, const void* pos, void* out, int B, int S, int C,
+                                 int vocab, void* stream) {
+    if (B <= 0 || S <= 0 || C <= 0 || C % 8 || vocab <= 0) return MC_ERR_SHAPE;
+    MC_LAUNCH(clip_embed_kernel, dim3(ew_blocks((long)B * S * (C / 8))), dim3(256), 0, (hipStream_t)stream, ids,
+              (const half_t*)tok, (const half_t*)pos, (half_t*)out, B, S, C, vocab);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_quick_gelu_f16(const void* in, void* out, long n, void* stream) {
+    if (n <= 0 || n % 8) return MC_ERR_SHAPE;
+    MC_LAUNCH(quick_gelu_kernel, dim3(ew_blocks(n / 8)), dim3(256), 0, (hipStream_t)stream, (const half_t*)in,
+              (half_t*)out, n);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }

@@ -25,6 +25,9 @@ SIGNATURES = {
     "mc_video_post_f32": [P, I, P, I, I, I, P],
     "mc_vae_sample_f16": [P, I, P, P, I, I, I, P],
     "mc_video_resize_u8_f16": [P, P, I, I, I, I, I, I, P],
+    "mc_attn_fwd_causal_f16": [P, P, P, I, I, I, P, I, I, I, I, I, F, P],
+    "mc_clip_embed_f16": [P, P, P, P, I, I, I, I, P],
+    "mc_quick_gelu_f16": [P, P, L, P],
     "mc_gemm_splitk_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P, I, P],
     "mc_gn_nchunk": [I],
     "mc_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, F, P, P, P],

@@ -193,6 +193,31 @@ def attn_fwd(q, k, v, Nq, Nk, heads, d, nbatch, kv_bdiv=1, scale=None, need_lse=
     return out, lse
 
 
+def attn_fwd_causal(q, k, v, N, heads, d, nbatch, scale=None, out=None):
+    """causal self-attention (CLIP text encoder): tokens [(nbatch N), heads*d]"""
+    scale = d ** -0.5 if scale is None else scale
+    if out is None:
+        out = empty((q.shape[0], heads * d), q)
+    lib.call("mc_attn_fwd_causal_f16", _p(q), _p(k), _p(v), _ld(q), _ld(k), _ld(v), _p(out), _ld(out), N, heads, d,
+             nbatch, float(scale), _stream(q))
+    return out
+
+
+def clip_embed(ids, tok, pos):
+    """ids int64 [B, S] -> fp16 [(B S), C] = token_embedding[ids] + position_embedding[:S]"""
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    B, S = ids.shape
+    out = empty((B * S, tok.shape[1]), tok)
+    lib.call("mc_clip_embed_f16", _p(ids), _p(_f16(tok)), _p(_f16(pos)), _p(out), B, S, tok.shape[1], tok.shape[0], _stream(tok))
+    return out
+
+
+def quick_gelu(x):
+    out = torch.empty_like(x)
+    lib.call("mc_quick_gelu_f16", _p(_f16(x)), _p(out), x.numel(), _stream(x))
+    return out
+
+
 def attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nbatch, kv_bdiv=1, scale=None, dq=None, dk=None, dv=None,
              need_dkv=True):
     scale = d ** -0.5 if scale is None else scale
