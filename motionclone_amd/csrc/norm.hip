@@ -428,8 +428,12 @@ static int make_src(GnSrc* s, const void* a, const void* b, int lda, int ldb, in
     return 1;
 }
 
+// chunks per frame of the two-stage GroupNorm kernels (grid = chunks x frames).  64-row chunks at the large levels; the
+// small levels (16x16, 8x8 latents) get shorter chunks so that 32 frames still put >= 256 workgroups on the chip:
+// with 64-row chunks a 16x16-level apply ran on 128 workgroups at 1.2 TB/s
 extern "C" int mc_gn_nchunk(int hw) {
-    int n = (hw + 63) / 64;
+    const int rows = hw >= 4096 ? 64 : (hw >= 1024 ? 32 : (hw >= 256 ? 16 : 8));
+    int n = (hw + rows - 1) / rows;
     if (n < 1) n = 1;
     if (n > 64) n = 64;
     return n;
