@@ -97,7 +97,16 @@ def is_emulated():
     return _is_emulated
 
 
+_FN = {}   # name -> bound ctypes function of the loaded library (cleared whenever the library changes)
+
+
 def call(name, *args):
-    rc = getattr(load(), name)(*args)
+    if _lib is None or _FN.get("__lib__") is not _lib:
+        _FN.clear()
+        _FN["__lib__"] = load()
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib, name)
+    rc = fn(*args)
     if rc != 0:
         raise RuntimeError("%s failed: %s (rc=%d)" % (name, ERRORS.get(rc, "unknown"), rc))

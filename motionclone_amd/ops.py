@@ -67,6 +67,8 @@ def empty(shape, like, dtype=torch.float16):
 
 
 # ---- GEMM family ---------------------------------------------------------------------------------
+_SPLIT_PLAN = {}   # (M, N, K, mode) -> mc_gemm_splitk_plan, memoised: one ctypes round trip less per launch
+
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
          rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0, splits=None,
          pad_front=True):
@@ -98,7 +100,13 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         _f32(bias)
         assert bias.shape[-1] == N
     if splits is None:
-        splits = 1 if (geglu or tile or v1 or deep or cfg) else lib.load().mc_gemm_splitk_plan(M, N, K, mode)
+        if geglu or tile or v1 or deep or cfg:
+            splits = 1
+        else:
+            key = (M, N, K, mode, lib.is_emulated())
+            splits = _SPLIT_PLAN.get(key)
+            if splits is None:
+                splits = _SPLIT_PLAN[key] = lib.load().mc_gemm_splitk_plan(M, N, K, mode)
     if splits > 1:
         ws = empty((splits * M * N,), a, torch.float32)
         lib.call("mc_gemm_splitk_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
