@@ -37,8 +37,9 @@ def gemm_kernel_name(mode, M, N, K=0):
     """Which kernel instance mc_gemm_f16 picks in auto mode (mirrors the heuristic in csrc/gemm.hip)."""
     modes = {ops.DENSE: "DENSE", ops.CONV_S1: "CONV_S1", ops.CONV_S2: "CONV_S2", ops.CONV_UP: "CONV_UP",
              ops.TCONV_S2: "TCONV_S2"}
-    if K and lib.load().mc_gemm_splitk_plan(M, N, K, mode) > 1:
-        return "gemm3_kernel<%s,128,320,2,2> split-K + reduce" % modes[mode]
+    plan = lib.load().mc_gemm_splitk_plan(M, N, K, mode) if K else 1
+    if plan > 1:
+        return "gemm3_kernel<%s,%s> split-K + reduce" % (modes[mode], "256,320,4,2" if (plan >> 8) == 1 else "128,320,2,2")
     if N % 320 == 0:
         if ((M + 255) // 256) * (N // 320) >= 224:
             return "gemm3_kernel<%s,256,320,4,2>" % modes[mode]

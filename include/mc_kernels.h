@@ -52,7 +52,8 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
 /* Split-K variant for small-M / deep-K problems (the 8x8 and 16x16-level 3x3 convs of unet_blocks.py:Downsample3D /
  * ResnetBlock3D at reference motionclone/models/resnet.py:110-209): K is cut into `splits` ranges computed by
  * separate workgroups into the fp32 workspace ws[splits][M][N]; a reduce kernel applies bias / residual.
- * mc_gemm_splitk_plan returns the number of ranges to use for a problem (1 = call mc_gemm_f16 instead). */
+ * mc_gemm_splitk_plan returns 1 (= call mc_gemm_f16 instead) or ranges | (geometry << 8): the number of K ranges and
+ * the gemm3 geometry to request in flags bits 12-15 (1: 256x320 tiles, 4: 128x320 tiles). */
 int mc_gemm_splitk_plan(int M, int N, int K, int mode);
 int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                        int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode, int Hs,

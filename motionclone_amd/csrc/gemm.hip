@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
 }
 }  // namespace mc
 
-// How many K ranges mc_gemm_splitk_f16 should be given for this problem (1 = use mc_gemm_f16).  Policy, measured on
+// How many K ranges mc_gemm_splitk_f16 should be given for this problem: returns 1 (= use mc_gemm_f16) or
+// splits | (geometry << 8), geometry = the gemm3 cfg to pass in flags bits 12-15.  Policy, measured on
 // MI355X: the 8x8 / 16x16-level 3x3 convs (M <= 4096 rows, K = 11520 or 23040) leave 128x320 tiles on a fraction of
 // the CUs or fall to 64x64 tiles at ~300 TFLOP/s; splitting K over up to 8 workgroups per tile fills the chip with
 // the efficient geometry and costs one fp32 round trip of the (small) output (8x8 level: 143 -> 95 us at B = 2,
@@ -340,12 +341,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int
 extern "C" int mc_gemm_splitk_plan(int M, int N, int K, int mode) {
     (void)mode;
     if (N % 320 || K < 2304 || M <= 0) return 1;
-    long tiles = (long)((M + 127) / 128) * (N / 320);
-    if (tiles >= 256) return 1;
-    int s = (int)(256 / tiles);
+    const int nk = K / BK;
+    long t1 = (long)((M + 255) / 256) * (N / 320), t4 = (long)((M + 127) / 128) * (N / 320);
+    if (t1 >= 224) return 1;                       // 256x320 tiles already fill the chip
+    int s, cfg;
+    if (t1 >= 64) {                                // 64..223 big tiles: keep the efficient geometry, 2-4 K ranges
+        s = (int)(256 / t1);
+        cfg = 1;
+    } else {                                       // fewer: 128x320 tiles, up to 8 K ranges
+        if (t4 >= 256) return 1;
+        s = (int)(256 / t4);
+        cfg = 4;
+    }
     if (s > 8) s = 8;
-    while (s > 1 && (K / BK) / s < 8) --s;
-    return s < 2 ? 1 : s;
+    while (s > 1 && nk / s < 8) --s;
+    return s < 2 ? 1 : (s | (cfg << 8));
 }
 
 // Same contract as mc_gemm_f16 (no GEGLU epilogue), K split into `splits` ranges.  ws: fp32 workspace of

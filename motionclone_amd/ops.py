@@ -107,6 +107,9 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
             splits = _SPLIT_PLAN.get(key)
             if splits is None:
                 splits = _SPLIT_PLAN[key] = lib.load().mc_gemm_splitk_plan(M, N, K, mode)
+            if splits > 1:      # plan = K ranges | (gemm3 geometry << 8)
+                flags |= (splits >> 8) << 12
+                splits &= 0xFF
     if splits > 1:
         ws = empty((splits * M * N,), a, torch.float32)
         lib.call("mc_gemm_splitk_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),

@@ -82,8 +82,10 @@ def test_gemm_split_k(backend, splits, cfg):
 def test_gemm_split_k_plan(backend):
     from motionclone_amd import lib
     L = lib.load()
-    assert L.mc_gemm_splitk_plan(2048, 1280, 11520, 1) == 4      # 8x8 level, B = 2: 64 tiles -> 4 ranges
-    assert L.mc_gemm_splitk_plan(1024, 1280, 23040, 1) == 8
+    assert L.mc_gemm_splitk_plan(2048, 1280, 11520, 1) == (4 | (4 << 8))   # 8x8 level, B = 2: 64 tiles of 128x320 -> 4 ranges
+    assert L.mc_gemm_splitk_plan(1024, 1280, 23040, 1) == (8 | (4 << 8))
+    assert L.mc_gemm_splitk_plan(8192, 1280, 11520, 1) == (2 | (1 << 8))   # 16x16 level, B = 2: 128 tiles of 256x320 -> 2 ranges
+    assert L.mc_gemm_splitk_plan(4096, 1280, 11520, 1) == (4 | (1 << 8))
     assert L.mc_gemm_splitk_plan(131072, 320, 2880, 1) == 1      # plenty of tiles
     assert L.mc_gemm_splitk_plan(2048, 1280, 1280, 0) == 1       # K too shallow
     assert L.mc_gemm_splitk_plan(2048, 1000, 11520, 0) == 1      # N not a multiple of 320
