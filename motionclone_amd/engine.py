@@ -200,9 +200,11 @@ class UNet3DEngine:
                                  for n in names]).to(self.dev).contiguous()
 
     def _time_bias(self, t, B, like):
-        """-> fp32 [B, sum Cout]: conv1.bias + time_emb_proj(silu(time_embedding(t)))  (resnet.py:191-195)"""
+        """-> fp32 [1, sum Cout]: conv1.bias + time_emb_proj(silu(time_embedding(t)))  (resnet.py:191-195).  The timestep
+        is one scalar for the whole batch (unet.py:386-391 broadcasts it), so the bias row is shared by every batch element:
+        one row is computed, and each resnet's slice of it is a contiguous view (no per-resnet copies)."""
         w = self.w
-        tt = torch.full((B,), float(t), dtype=torch.float32, device=self.dev)
+        tt = torch.full((1,), float(t), dtype=torch.float32, device=self.dev)
         e = ops.timestep_embed(tt, self.cfg["block_out_channels"][0], like)
         e = ops.gemm(e, w.lin("time_embedding.linear_1.weight"), bias=w.vec("time_embedding.linear_1.bias").unsqueeze(0))
         e = ops.gemm(ops.silu(e), w.lin("time_embedding.linear_2.weight"),
@@ -240,12 +242,15 @@ class UNet3DEngine:
         eps = cfg["norm_eps"]
         fr, hw, H, W = geo.frames, geo.hw, geo.H, geo.W
         off, cout = self.temb_off[p]
-        tb = tb_all[:, off:off + cout].contiguous()
+        tb = tb_all[:, off:off + cout]        # one shared row [1, cout] (a contiguous view), or one row per batch element
+        rpb = 0
+        if tb_all.shape[0] > 1:
+            tb, rpb = tb.contiguous(), geo.F * hw
         g1w, b1 = w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias")
         g2, b2 = w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias")
         st1 = ops.gn_stats(x, x2, fr, hw, eps)
         h1 = ops.gn_apply(x, x2, st1, g1w, b1, True, fr, hw)
-        h2 = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=geo.F * hw, mode=CONV_S1,
+        h2 = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=rpb, mode=CONV_S1,
                       geom=(H, W, H, W), m_out=geo.T)
         del h1
         st2 = ops.gn_stats(h2, None, fr, hw, eps)
