@@ -283,7 +283,7 @@ def main():
     # hipGraph replay of the same videos (sampler.enable_graphs), measured after and outside the timed region: the
     # contract's `value` stays on the eager path, whose GEMM launches carry the HIP events of the roofline object
     graph_info = None
-    if rank == 0 and not args.no_graphs:
+    if rank == 0 and world == 1 and not args.no_graphs:   # single-GPU runs only: the scaling runs stay minimal
         smg = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                                  num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE,
                                  controlnet=ceng).enable_graphs()
@@ -306,7 +306,7 @@ def main():
                           note="30 captured step graphs replayed; extraction eager; not part of `value`")
         del smg
     vae_info = None
-    if rank == 0 and not args.no_vae:
+    if rank == 0 and world == 1 and not args.no_vae:
         vae_info = vae_extras(dev, out, args.frames, args.size)
     if rank == 0:
         gsec = [e0.elapsed_time(e1) / 1e3 for g, e0, e1 in step_events if g]
