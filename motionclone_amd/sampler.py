@@ -41,6 +41,7 @@ class MotionCloneSampler:
         self.weight = float(motion_guidance_weight)
         self.warm, self.cool = warm_up_steps, cool_up_steps
         self.N, self.G = num_inference_steps, guidance_steps
+        self.guidance_scale = float(guidance_scale)   # fraction of the train timesteps covered by the guided steps
         self.timesteps = uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale)
         self.acp = ddim_alphas_cumprod()
         self.final_alpha = 1.0

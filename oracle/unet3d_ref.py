@@ -242,6 +242,9 @@ def resnet_block(sd, p, x, temb, cfg):
     return x + h
 
 
+MHA_MAX_SCORE_BYTES = 12 << 30   # no-grad attention is evaluated in batch chunks above this score-matrix size
+
+
 def _mha(q, k, v, heads):
     """CrossAttention._attention with head split/merge (attention.py:367-379,461-490)."""
     Bq, Nq, C = q.shape
@@ -249,6 +252,14 @@ def _mha(q, k, v, heads):
     qh = q.reshape(Bq, Nq, heads, d).transpose(1, 2)
     kh = k.reshape(Bq, -1, heads, d).transpose(1, 2)
     vh = v.reshape(Bq, -1, heads, d).transpose(1, 2)
+    score_bytes = Bq * heads * Nq * kh.shape[2] * q.element_size()
+    if score_bytes > MHA_MAX_SCORE_BYTES and not torch.is_grad_enabled():
+        # same arithmetic per (batch, head) slice, evaluated a few batch elements at a time: the reference's
+        # `_attention` materialises [B*heads, N, N] at once (attention.py:461-490), which at 32 f x 96 x 96 is 87 GB in fp32
+        step = max(1, int(Bq * MHA_MAX_SCORE_BYTES // score_bytes))
+        out = [torch.softmax(qh[i:i + step] @ kh[i:i + step].transpose(-1, -2) * d ** -0.5, dim=-1) @ vh[i:i + step]
+               for i in range(0, Bq, step)]
+        return torch.cat(out, 0).transpose(1, 2).reshape(Bq, Nq, C)
     p = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1)
     return (p @ vh).transpose(1, 2).reshape(Bq, Nq, C)
 

@@ -1,0 +1,183 @@
+"""Shared checks of the HIP engine against the oracle, size-agnostic: the same functions run the tiny UNet on the host
+simulator (CPU suite) and the SD-1.5-width UNet at BASELINE shapes with the oracle in fp32 ON THE MI355X
+(tests/test_fullsize_parity.py).  Test infrastructure only.
+
+Inputs follow SURVEY.md 8(d): latents ~ N(0,1) seed 2025 (prepare_latents, pipeline_animation.py:316), text ~ N(0,1)
+[2, n, dim] seed 7 (row 0 = uncond), reference-video latents 0.18215 N(0,1) seed 11, extraction noise seed 2025."""
+import contextlib
+import json
+import os
+
+import torch
+
+from motionclone_amd import ops
+from oracle import guidance_ref as G
+from oracle import unet3d_ref as U
+
+HP = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10)
+TOL_FWD, TOL_GRAD, TOL_LOSS = 2e-2, 5e-2, 3e-2      # relative L2 (fp16 storage vs fp32 oracle); loss relative
+TIE_GAP = 4e-3                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
+
+_REPORT = {}
+
+
+def report(key, **vals):
+    """collect measured errors; written to gpurun_out/parity_r02.json (copied into DESIGN.md 4 by hand)"""
+    _REPORT.setdefault(key, {}).update({k: (float(v) if hasattr(v, "__float__") else v) for k, v in vals.items()})
+    try:
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open(os.path.join("gpurun_out", "parity_r02.json"), "w") as f:
+            json.dump(_REPORT, f, indent=1, sort_keys=True)
+    except OSError:
+        pass
+    print("PARITY", key, json.dumps({k: _REPORT[key][k] for k in vals}, sort_keys=True))
+
+
+@contextlib.contextmanager
+def oracle_mode(dev):
+    """fp32 oracle on `dev`.  On the GPU the convolutions go through PyTorch's own im2col + GEMM path (MIOpen off): the box
+    is fresh, MIOpen has no precompiled gfx950 kernels and would JIT every conv shape; fp32 matmuls stay full precision."""
+    if dev.type == "cuda":
+        old = torch.backends.cuda.matmul.allow_tf32
+        torch.backends.cuda.matmul.allow_tf32 = False
+        use_miopen = os.environ.get("MC_ORACLE_MIOPEN", "0") == "1"
+        with torch.backends.cudnn.flags(enabled=use_miopen, benchmark=False, deterministic=True):
+            yield
+        torch.backends.cuda.matmul.allow_tf32 = old
+    else:
+        yield
+
+
+def synth_inputs(cfg, F, H, W, dev, n_text=77):
+    g = lambda s: torch.Generator(device=dev).manual_seed(s)   # noqa: E731
+    lat = torch.randn((1, 4, F, H, W), generator=g(2025), device=dev, dtype=torch.float32).half()
+    text = torch.randn((2, n_text, cfg["cross_attention_dim"]), generator=g(7), device=dev).half()
+    vid = (0.18215 * torch.randn((1, 4, F, H, W), generator=g(11), device=dev)).half()
+    noise = torch.randn((1, 4, F, H, W), generator=g(2025), device=dev, dtype=torch.float32).half()
+    return lat, text, vid, noise
+
+
+def rel(a, b):
+    a, b = a.float(), b.float().to(a.device)
+    return ((a - b).norm() / b.norm().clamp_min(1e-20)).item()
+
+
+def to_lat(eps_tokens, B, F, H, W):
+    return ops.cl_to_latent(eps_tokens, B, 4, F, H, W).float()
+
+
+def oracle_weights(sd16, dev):
+    """the engine's fp16 weights as fp32 tensors for the oracle: both sides share bit-identical parameters"""
+    return {k: v.to(dev, torch.float32) for k, v in sd16.items()}
+
+
+def check_forward_b2(eng, sdo, cfg, lat, text, t, key):
+    B, _, F, H, W = (2,) + tuple(lat.shape[1:])
+    eps = eng.forward(lat.expand(2, -1, -1, -1, -1), t, text)
+    with torch.no_grad(), oracle_mode(lat.device):
+        ref = U.unet_forward(sdo, cfg, lat.float().expand(2, -1, -1, -1, -1), t, text.float())
+    got = to_lat(eps, 2, F, H, W)
+    e = rel(got, ref)
+    report(key, forward_b2_rel=e, eps_abs_max=ref.abs().max())
+    assert torch.isfinite(got).all()
+    assert e < TOL_FWD, e
+    return got, ref
+
+
+def flip_stats(idx, val, prob):
+    """idx/val: engine top-1 [BN, heads, F, 1]; prob: oracle P fp32 [BN, heads, F, F].
+    -> (#flips, total, max oracle gap over flips, max |val - oracle top value|)"""
+    top_v, top_i = torch.topk(prob, k=1, dim=-1)
+    idx = idx.to(prob.device).long()
+    mism = idx != top_i
+    alt = torch.gather(prob, -1, idx)
+    gap = (top_v - alt)[mism]
+    return int(mism.sum()), mism.numel(), (float(gap.max()) if gap.numel() else 0.0), \
+        float((val.float().to(prob.device) - top_v).abs().max())
+
+
+def check_extraction(eng, smp, sdo, cfg, vid, noise, text, key, ctrl=None, res=None):
+    """obtain_motion_representation's model part: exact flip count of the uint8 arg-max, every flip proven a tie"""
+    rep = smp.extract(vid, noise, text[0:1], add_noise_step=400, ctrl=ctrl)
+    noisy = smp.add_noise(400, vid, noise).float()
+    rec = {}
+    with torch.no_grad(), oracle_mode(vid.device):
+        U.unet_forward(sdo, cfg, noisy, 400, text[0:1].float(), only_motion_feature=True, record=rec,
+                       down_residuals=res[0] if res else None, mid_residual=res[1] if res else None)
+        prob = G.temp_attn_prob(rec, cfg["motion_heads"])
+    ref = G.motion_representation(prob)
+    assert list(rep) == list(ref)
+    flips = total = 0
+    worst_gap = worst_val = 0.0
+    for k in ref:
+        v, i = rep[k]
+        assert v.shape == ref[k][0].shape and i.dtype == torch.uint8
+        n, tot, gap, dv = flip_stats(i, v, prob[k])
+        flips, total = flips + n, total + tot
+        worst_gap, worst_val = max(worst_gap, gap), max(worst_val, dv)
+    report(key, extraction_flips=flips, extraction_rows=total, extraction_flip_max_gap=worst_gap,
+           extraction_value_abs_max_err=worst_val)
+    assert worst_gap <= TIE_GAP, "an arg-max flip that is not a tie: gap %g" % worst_gap
+    assert worst_val < 5e-3
+    assert flips <= 0.02 * total
+    return rep, ref, prob
+
+
+def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, ctrl=None, res_u=None, res_c=None):
+    ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
+    assert smp.timesteps.tolist() == ts.tolist()
+    hp = dict(HP, guidance_steps=smp.G)
+    B, _, F, H, W = lat.shape
+    aux = {}
+    nxt = smp.step(lat, step_index, text, eng.prepare_representation(rep_ref), aux=aux, ctrl=ctrl)
+    with oracle_mode(lat.device):
+        ref_nxt, ref_aux = G.guided_step(sdo, cfg, lat.float(), step_index, ts, text.float(), rep_ref, hp,
+                                         res_u=res_u, res_c=res_c)
+    e = dict(eps_c=rel(to_lat(aux["eps_c"], 1, F, H, W), ref_aux["eps_c"]),
+             eps_u=rel(to_lat(aux["eps_u"], 1, F, H, W), ref_aux["eps_u"]),
+             loss=abs(float(aux["loss"]) - float(ref_aux["loss"])) / abs(float(ref_aux["loss"])),
+             grad=rel(aux["grad"], ref_aux["grad"]), latents=rel(nxt, ref_nxt),
+             loss_value=float(ref_aux["loss"]), grad_abs_max=float(ref_aux["grad"].abs().max()))
+    report(key, **{"guided_" + k: v for k, v in e.items()})
+    assert torch.isfinite(aux["grad"]).all() and torch.isfinite(nxt.float()).all()
+    assert e["eps_c"] < TOL_FWD and e["eps_u"] < TOL_FWD, e
+    assert e["loss"] < TOL_LOSS, e
+    assert e["grad"] < TOL_GRAD, e
+    assert e["latents"] < TOL_FWD, e
+    return nxt, ref_nxt
+
+
+def smp_guidance_scale(smp):
+    return smp.guidance_scale
+
+
+def check_plain_step(eng, smp, sdo, cfg, lat, text, step_index, key, ctrl=None, res=None):
+    ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
+    nxt = smp.step(lat, step_index, text, {}, ctrl=ctrl)
+    with oracle_mode(lat.device):
+        ref_nxt, _ = G.plain_step_full(sdo, cfg, lat.float(), step_index, ts, text.float(), HP["cfg_scale"], res=res)
+    e = rel(nxt, ref_nxt)
+    report(key, **{"plain_step_%d_latents" % step_index: e})
+    assert e < TOL_FWD, e
+    return nxt, ref_nxt
+
+
+def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol):
+    """N-step loop (sample_video, motionclone_functions.py:164-166): each side follows its own trajectory"""
+    ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
+    hp = dict(HP, guidance_steps=smp.G)
+    rep_dev = eng.prepare_representation(rep_ref)
+    x, xr = lat, lat.float()
+    drift = []
+    for i in range(smp.N):
+        x = smp.step(x, i, text, rep_dev)
+        with oracle_mode(lat.device):
+            if i < smp.G:
+                xr, _ = G.guided_step(sdo, cfg, xr, i, ts, text.float(), rep_ref, hp)
+            else:
+                xr, _ = G.plain_step_full(sdo, cfg, xr, i, ts, text.float(), hp["cfg_scale"])
+        drift.append(rel(x, xr))
+    report(key, loop_drift=[round(d, 6) for d in drift], loop_steps=smp.N, loop_guided=smp.G)
+    assert torch.isfinite(x.float()).all()
+    assert drift[-1] < tol, drift
+    return drift

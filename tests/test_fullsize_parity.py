@@ -1,0 +1,167 @@
+"""Parity at the sizes that are benchmarked: SD-1.5 widths (320/640/1280, head dims 40/80/160) + AnimateDiff motion
+modules at BASELINE's shapes, HIP engine vs the oracle run in fp32 ON THE SAME MI355X (the oracle is plain torch; its
+convolutions use PyTorch's im2col + GEMM path, see parity_util.oracle_mode).
+
+  config 1 shape  16 f x 32 x 32 latent (256^2),  schedule (10, 5, 0.3)  - forward, extraction, guided, plain, full loop
+  config 2 shape  16 f x 64 x 64 latent (512^2),  schedule (30, 18, 0.4) - forward, extraction, guided, plain, last step
+  config 4        config 2 + SparseCtrl (i2v_rgb), schedule (30, 12, 0.3) - encoder residuals, extraction, guided, plain
+  config 5 shape  32 f x 96 x 96 latent (768^2)                          - B = 1 forward (two 16-wide frame tiles)
+  second witness  the oracle in fp16 on the GPU (= the reference's own arithmetic through stock PyTorch-ROCm)
+
+Weights: synthetic seed 1234 with motion proj_out re-randomised; both sides use the same fp16-rounded
+parameters.  Tolerances (parity_util): forward / latents 2e-2 relative L2, gradient 5e-2, loss 3 %, arg-max flips
+must be ties (oracle gap <= 4e-3) and are counted exactly.  Measured errors are written to gpurun_out/parity_r02.json.
+"""
+import pytest
+import torch
+
+import parity_util as PU
+from motionclone_amd import spec
+from motionclone_amd.engine import ControlNetEngine, UNet3DEngine, default_config
+from motionclone_amd.sampler import MotionCloneSampler
+from oracle import guidance_ref as G
+from oracle import unet3d_ref as U
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def world():
+    from motionclone_amd import lib
+    lib._lib = None
+    lib._is_emulated = False
+    lib.load()
+    dev = torch.device("cuda:0")
+    cfg = default_config()
+    assert {k: cfg[k] for k in U.SD15_CONFIG} == U.SD15_CONFIG
+    sd, _ = spec.synthetic_state_dict(cfg, seed=1234, device=dev)
+    eng = UNet3DEngine(sd, cfg, dev)
+    sdo = PU.oracle_weights(sd, dev)
+    return dev, cfg, sd, eng, sdo
+
+
+def sampler(eng, N, Gs, gs, controlnet=None):
+    return MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gs, controlnet=controlnet, **PU.HP)
+
+
+@pytest.mark.parametrize("shape,sched", [((16, 32, 32), (10, 5, 0.3)), ((16, 64, 64), (30, 18, 0.4))], ids=["cfg1", "cfg2"])
+def test_forward_extraction_guided_plain(world, shape, sched):
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = shape
+    key = "cfg1_16f_256" if H == 32 else "cfg2_16f_512"
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, *sched)
+    PU.check_forward_b2(eng, sdo, cfg, lat, text, int(smp.timesteps[0]), key)
+    _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key)
+    nxt2, _ = PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
+    PU.check_plain_step(eng, smp, sdo, cfg, nxt2, text, smp.N - 1, key)      # last step: alpha_prev = final_alpha_cumprod
+    torch.cuda.empty_cache()
+
+
+def test_full_loop_config1(world):
+    """the whole config-1 schedule (10 steps, 5 guided): engine and oracle each follow their own trajectory"""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 16, 32, 32
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 10, 5, 0.3)
+    with PU.oracle_mode(dev):
+        rep_ref = G.extract_representation(sdo, cfg, vid.float(), noise.float(), text[0:1].float())
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg1_16f_256", tol=5e-2)
+    torch.cuda.empty_cache()
+
+
+def test_forward_32_frames_768(world):
+    """config-5 shape: 32 f x 96 x 96 latent, B = 1 (level-0 self-attention over 9216 tokens, F = 32 temporal tiles)"""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 32, 96, 96
+    lat, text, _, _ = PU.synth_inputs(cfg, F, H, W, dev)
+    eps = eng.forward(lat, 601, text[1:2])
+    got = PU.to_lat(eps, 1, F, H, W)
+    del eps
+    with torch.no_grad(), PU.oracle_mode(dev):
+        ref = U.unet_forward(sdo, cfg, lat.float(), 601, text[1:2].float())
+    e = PU.rel(got, ref)
+    PU.report("cfg5_32f_768", forward_b1_rel=e)
+    assert e < PU.TOL_FWD, e
+    torch.cuda.empty_cache()
+
+
+def test_sparsectrl_config4(world):
+    """i2v_rgb: SparseCtrl encoder residuals, extraction / guided / plain step with them (motionclone_functions.py:176-208)"""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 16, 64, 64
+    key = "cfg4_sparsectrl"
+    csd = spec.synthetic_controlnet_state_dict(cfg, seed=4321, device=dev)
+    ceng = ControlNetEngine(csd, cfg, dev)
+    csdo = PU.oracle_weights(csd, dev)
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 30, 12, 0.3, controlnet=ceng)
+    cond = torch.zeros_like(vid)
+    mask = torch.zeros_like(vid[:, :1])
+    cond[:, :, 0] = vid[:, :, 0]
+    mask[:, :, 0] = 1
+    scale = 1.0
+    ctrl = dict(cond=cond, mask=mask, scale=scale)
+    t0 = int(smp.timesteps[0])
+
+    def tok(t):
+        return t.permute(0, 2, 3, 4, 1).reshape(-1, t.shape[1])
+    down, mid = ceng.forward((2, 4, F, H, W), t0, text, cond, mask, scale)
+    with torch.no_grad(), PU.oracle_mode(dev):
+        d_ref, m_ref = U.controlnet_forward(csdo, cfg, (2, 4, F, H, W), t0, text.float(), cond.float(), mask.float(), scale)
+    errs = [PU.rel(a, tok(b)) for a, b in zip(down, d_ref)] + [PU.rel(mid, tok(m_ref))]
+    PU.report(key, controlnet_residual_rel_max=max(errs))
+    assert len(down) == 12 and max(errs) < PU.TOL_FWD, errs
+    del down, mid
+    # extraction with the encoder (uncond text, t = 400)
+    noisy = smp.add_noise(400, vid, noise).float()
+    with torch.no_grad(), PU.oracle_mode(dev):
+        dr, mr = U.controlnet_forward(csdo, cfg, noisy.shape, 400, text[0:1].float(), cond.float(), mask.float(), scale)
+    _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key, ctrl=ctrl, res=(dr, mr))
+    res_u = ([d[[0]] for d in d_ref], m_ref[[0]])
+    res_c = ([d[[1]] for d in d_ref], m_ref[[1]])
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, ctrl=ctrl, res_u=res_u, res_c=res_c)
+    tG = int(smp.timesteps[smp.G])
+    with torch.no_grad(), PU.oracle_mode(dev):
+        d3, m3 = U.controlnet_forward(csdo, cfg, (2, 4, F, H, W), tG, text.float(), cond.float(), mask.float(), scale)
+    PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key, ctrl=ctrl, res=(d3, m3))
+    torch.cuda.empty_cache()
+
+
+def test_fp16_oracle_second_witness(world):
+    """the oracle in fp16 on the GPU is the reference's own arithmetic through stock PyTorch-ROCm.  Its
+    distance to the fp32 oracle is the 'fp16 tolerance' of the claim; the engine (fp16 storage, fp32 accumulation) must
+    not be further away than the tolerance, and is reported next to it.  A finite fp16 forward also shows that no
+    activation of the reference reaches the fp16 range limit at this size, i.e. the saturating conversions of the
+    kernels (mc_common.hpp to_half) never act where the reference would have produced inf."""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 16, 64, 64
+    key = "cfg2_16f_512"
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 30, 18, 0.4)
+    t = int(smp.timesteps[0])
+    sd16 = {k: v.half() for k, v in sd.items()}
+    with torch.no_grad(), PU.oracle_mode(dev):
+        ref32 = U.unet_forward(sdo, cfg, lat.float().expand(2, -1, -1, -1, -1), t, text.float())
+        ref16 = U.unet_forward(sd16, cfg, lat.expand(2, -1, -1, -1, -1), t, text)
+    assert torch.isfinite(ref16).all(), "the reference's fp16 arithmetic overflows at this size"
+    got = PU.to_lat(eng.forward(lat.expand(2, -1, -1, -1, -1), t, text), 2, F, H, W)
+    e16, eng_e = PU.rel(ref16, ref32), PU.rel(got, ref32)
+    PU.report(key, witness_fp16_oracle_forward_rel=e16, witness_engine_forward_rel=eng_e,
+              witness_engine_vs_fp16_oracle=PU.rel(got, ref16))
+    assert eng_e < PU.TOL_FWD
+    # extraction in fp16: how many arg-max indices the reference's own arithmetic flips against fp32
+    noisy = smp.add_noise(400, vid, noise)
+    rec32, rec16 = {}, {}
+    with torch.no_grad(), PU.oracle_mode(dev):
+        U.unet_forward(sdo, cfg, noisy.float(), 400, text[0:1].float(), only_motion_feature=True, record=rec32)
+        U.unet_forward(sd16, cfg, noisy, 400, text[0:1], only_motion_feature=True, record=rec16)
+        p32 = G.temp_attn_prob(rec32, cfg["motion_heads"])
+        rep16 = G.motion_representation(G.temp_attn_prob(rec16, cfg["motion_heads"]))
+    flips = total = 0
+    for k in p32:
+        n, tot, gap, _ = PU.flip_stats(rep16[k][1], rep16[k][0], p32[k])
+        flips, total = flips + n, total + tot
+    PU.report(key, witness_fp16_oracle_extraction_flips=flips, witness_rows=total)
+    torch.cuda.empty_cache()
