@@ -30,7 +30,10 @@ def uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale, num_tr
 class MotionCloneSampler:
     def __init__(self, engine, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                  num_inference_steps=30, guidance_steps=18, guidance_scale=0.4, score_guidance_scale=1.0,
-                 controlnet=None, batch_guided=True):
+                 controlnet=None, batch_guided=True, timesteps=None, alphas_cumprod=None, final_alpha_cumprod=1.0):
+        """`timesteps` / `alphas_cumprod` / `final_alpha_cumprod`: the state of an already configured scheduler (what the
+        reference reads at motionclone_functions.py:213-214,326-336); by default the 'uneven' table of the arguments and the
+        DDIM tables of configs/model_config/model_config.yaml:16-21."""
         self.engine = engine
         self.dev = engine.dev
         # True: guided steps run eps_u / eps_c as one B = 2 forward (same per-sample arithmetic as the reference's
@@ -42,9 +45,13 @@ class MotionCloneSampler:
         self.warm, self.cool = warm_up_steps, cool_up_steps
         self.N, self.G = num_inference_steps, guidance_steps
         self.guidance_scale = float(guidance_scale)   # fraction of the train timesteps covered by the guided steps
-        self.timesteps = uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale)
-        self.acp = ddim_alphas_cumprod()
-        self.final_alpha = 1.0
+        if timesteps is None:
+            self.timesteps = uneven_timesteps(num_inference_steps, guidance_steps, guidance_scale)
+        else:
+            self.timesteps = np.asarray(torch.as_tensor(timesteps).cpu(), dtype=np.int64)
+            self.N = len(self.timesteps)
+        self.acp = ddim_alphas_cumprod() if alphas_cumprod is None else torch.as_tensor(alphas_cumprod).detach().float().cpu()
+        self.final_alpha = float(final_alpha_cumprod)
         self.score_gs = float(score_guidance_scale)
         self._graphs = None      # step index -> (hipGraph, static input, static output); see enable_graphs()
         self._graph_pool = None

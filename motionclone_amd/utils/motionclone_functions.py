@@ -40,16 +40,26 @@ def add_noise(self, timestep, x_0, noise_pred):
 
 
 def _sampler(pipe):
-    """MotionCloneSampler over the pipeline's unet engine, configured from pipe.input_config (cached)."""
+    """MotionCloneSampler over the pipeline's unet engine.  Hyper-parameters come from pipe.input_config; the timestep
+    table, alphas_cumprod and final_alpha_cumprod are READ FROM pipe.scheduler, as the reference does (:213-214,326-336),
+    so any spacing type / beta schedule / set_alpha_to_one the scheduler was configured with is honoured.  Cached."""
     c = pipe.input_config
+    sch = pipe.scheduler
+    ts = tuple(int(t) for t in torch.as_tensor(sch.timesteps).cpu().tolist())
+    acp = torch.as_tensor(sch.alphas_cumprod).detach().float().cpu()
+    final = float(getattr(sch, "final_alpha_cumprod", 1.0))
+    if len(ts) != int(c.inference_steps):
+        raise ValueError("scheduler holds %d timesteps but input_config.inference_steps = %d: run "
+                         "scheduler.customized_set_timesteps first" % (len(ts), int(c.inference_steps)))
     key = (id(pipe.unet.engine()), c.cfg_scale, c.motion_guidance_weight, c.warm_up_steps, c.cool_up_steps,
-           c.inference_steps, c.guidance_steps, c.guidance_scale)
+           c.inference_steps, c.guidance_steps, c.guidance_scale, ts, hash(acp.numpy().tobytes()), final)
     if getattr(pipe, "_mc_sampler_key", None) != key:
         pipe._mc_sampler = MotionCloneSampler(pipe.unet.engine(), cfg_scale=c.cfg_scale,
                                               motion_guidance_weight=c.motion_guidance_weight,
                                               warm_up_steps=c.warm_up_steps, cool_up_steps=c.cool_up_steps,
                                               num_inference_steps=c.inference_steps, guidance_steps=c.guidance_steps,
-                                              guidance_scale=c.guidance_scale)
+                                              guidance_scale=c.guidance_scale, timesteps=ts, alphas_cumprod=acp,
+                                              final_alpha_cumprod=final)
         pipe._mc_sampler_key = key
     return pipe._mc_sampler
 
@@ -129,6 +139,9 @@ def compute_temp_loss(self, temp_attn_prob_control_dict):
 def single_step_video(self, noisy_latents, step_index, step_t, extra_step_kwargs):
     """:173-257 (guided branch while step_index < guidance_steps, else one B=2 forward)"""
     smp = _sampler(self)
+    if int(step_t) != int(smp.timesteps[step_index]):
+        raise ValueError("step_t %d is not scheduler.timesteps[%d] = %d" % (int(step_t), step_index,
+                                                                            int(smp.timesteps[step_index])))
     ctrl = None
     if getattr(self, "add_controlnet", False):   # :176-197: condition latents placed at image_index, mask = 1 there
         smp.controlnet = self.controlnet.engine()
