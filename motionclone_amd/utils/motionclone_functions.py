@@ -173,7 +173,7 @@ def sample_video(self, eta: float = 0.0, generator=None, noisy_latents: Optional
         imgs = []
         for path in cfg.condition_image_path_list:       # :112-119 (Resize + ToTensor), then VAE encode (:121-126)
             im = Image.open(path).convert("RGB").resize((cfg.width, cfg.height), Image.BILINEAR)
-            imgs.append(torch.from_numpy(_np.asarray(im)).permute(2, 0, 1).float() / 255.0)
+            imgs.append(torch.from_numpy(_np.array(im)).permute(2, 0, 1).float() / 255.0)
         px = torch.stack(imgs).to(dtype=self.vae.dtype, device=self.vae.device)
         lat = self.vae.encode(px * 2.0 - 1.0).latent_dist.sample() * self.vae.config.scaling_factor
         self.controlnet_images = lat.unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()

@@ -244,7 +244,7 @@ def install_recorders(rec):
     fwd = UNet3DConditionModel.forward
 
     def forward(self, sample, timestep, encoder_hidden_states, *a, **k):
-        if k.get("only_motion_feature"):
+        if k.get("only_motion_feature", a[5] if len(a) > 5 else False):
             rec["extract"] = dict(noisy=sample.detach().clone(), t=int(timestep), text=encoder_hidden_states.detach().clone())
         return fwd(self, sample, timestep, encoder_hidden_states, *a, **k)
     UNet3DConditionModel.forward = forward

@@ -1,0 +1,133 @@
+"""The drop-in boundary for real: the UNMODIFIED reference entry scripts
+/root/reference/t2v_video_sample.py and i2v_video_sample.py run `main(args)` against this repo's `motionclone/`
+package (tests/entry_harness.py, a child process: tiny checkpoints / configs / 4-frame video written to a tmp dir,
+kernels on the host simulator), and what they produced is checked against the oracle:
+
+  * the motion representation `.pt` written by obtain_motion_representation and read back by sample_video
+    (torch.save -> torch.load round trip, motionclone_functions.py:81,154): keys, dtypes, shapes, values / indices;
+  * the latents after the step loop vs the oracle loop from the same start (with the SparseCtrl residuals for i2v);
+  * the frames handed to imageio vs the oracle VAE decode of those latents;
+  * the text embeddings vs the real transformers.CLIPTextModel on the script's own token ids.
+
+Runs only where the reference tree exists (this container)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import guidance_ref as G
+from oracle import reference_shim as shim
+from oracle import unet3d_ref as U
+from oracle import vae_ref as V
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.skipif(not shim.available(), reason="reference tree not present")
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
+
+
+def run_harness(kind, work):
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), kind, str(work)],
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=str(work))
+    assert r.returncode == 0 and "ENTRY_OK" in r.stdout, r.stdout[-4000:]
+    return torch.load(os.path.join(str(work), "record.pt"))
+
+
+@pytest.mark.parametrize("kind", ["t2v", "i2v"])
+def test_unmodified_entry_script_matches_oracle(kind, tmp_path):
+    import entry_harness as EH
+    rec = run_harness(kind, tmp_path)
+    cfg = dict(U.TINY_CONFIG)
+    sd = {k: v.half().float() for k, v in U.random_state_dict(cfg, seed=1234).items()}
+    N, Gs, gs = EH.STEPS, EH.GUIDED, EH.GSCALE
+
+    # quirk 2: the yaml key is `postive_prompt`, the script reads `positive_prompt` -> the suffix is never appended
+    assert [os.path.basename(p) for p in rec["videos"]] == ["clip_a_cat_runs42_42.mp4"]
+
+    # ---- the .pt written by the script and loaded back by sample_video ------------------------------------------------
+    pt = torch.load(os.path.join(str(tmp_path), "motion_representation", "clip.pt"))
+    names = ["up_blocks.1.motion_modules.%d.temporal_transformer.transformer_blocks.0.attention_blocks.%d" % (j, a)
+             for j in range(3) for a in range(2)]
+    assert list(pt) == names
+    ex = rec["extract"]
+    assert ex["t"] == 400 and ex["noisy"].shape == (1, 4, EH.F, 8, 8)
+    res = None
+    csd = None
+    if kind == "i2v":
+        csd = {k: v.half().float() for k, v in U.random_controlnet_state_dict(cfg).items()}
+        c0 = rec["controlnet_calls"][0]
+        assert c0["t"] == 400 and c0["B"] == 1 and abs(c0["scale"] - 0.8) < 1e-6
+        assert float(c0["mask"][:, :, 0].min()) == 1.0 and float(c0["mask"][:, :, 1:].abs().max()) == 0.0
+        with torch.no_grad():
+            res = U.controlnet_forward(csd, cfg, ex["noisy"].shape, 400, ex["text"].float(), c0["cond"].float(),
+                                       c0["mask"].float(), 0.8)
+    rc = {}
+    with torch.no_grad():
+        U.unet_forward(sd, cfg, ex["noisy"].float(), 400, ex["text"].float(), only_motion_feature=True, record=rc,
+                       down_residuals=res[0] if res else None, mid_residual=res[1] if res else None)
+        prob = G.temp_attn_prob(rc, cfg["motion_heads"])
+    ref_rep = G.motion_representation(prob)
+    for k in names:
+        v, i = pt[k]
+        assert v.dtype == torch.float16 and i.dtype == torch.uint8 and v.device.type == "cpu"
+        assert v.shape == ref_rep[k][0].shape == (4, cfg["motion_heads"], EH.F, 1) and i.shape == v.shape
+        assert (v.float() - ref_rep[k][0]).abs().max() < 5e-3
+        mism = i != ref_rep[k][1]
+        if mism.any():
+            alt = torch.gather(prob[k], -1, i.long())
+            assert ((ref_rep[k][0] - alt)[mism] < 4e-3).all()
+
+    # ---- the step loop ---------------------------------------------------------------------------------------------------
+    lp = rec["loop"]
+    assert lp["steps_run"] == N and lp["G"] == Gs and lp["timesteps"] == G.uneven_timesteps(N, Gs, gs).tolist()
+    ts = G.uneven_timesteps(N, Gs, gs)
+    hp = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10, guidance_steps=Gs)
+    rep_cpu = {k: [a.float(), b] for k, (a, b) in pt.items()}
+    x, text = lp["lat0"].float(), lp["text"].float()
+    assert (kind == "i2v") == (lp["ctrl"] is not None)
+    for s in range(N):
+        d = m = None
+        if kind == "i2v":
+            with torch.no_grad():
+                d, m = U.controlnet_forward(csd, cfg, (2, 4, EH.F, 8, 8), int(ts[s]), text, lp["ctrl"]["cond"].float(),
+                                            lp["ctrl"]["mask"].float(), 0.8)
+        if s < Gs:
+            x, _ = G.guided_step(sd, cfg, x, s, ts, text, rep_cpu, hp,
+                                 res_u=([t[[0]] for t in d], m[[0]]) if d else None,
+                                 res_c=([t[[1]] for t in d], m[[1]]) if d else None)
+        else:
+            x, _ = G.plain_step_full(sd, cfg, x, s, ts, text, 7.5, res=(d, m) if d else None)
+    assert rel(lp["last"], x) < 3e-2, rel(lp["last"], x)
+
+    # ---- decoded video handed to imageio.mimwrite --------------------------------------------------------------------
+    frames = np.load(rec["videos"][0] + ".npy")
+    assert frames.dtype == np.uint8 and frames.shape == (EH.F, EH.PX, EH.PX, 3)
+    vcfg = dict(V.TINY_VAE_CONFIG)
+    vsd = {k: v.half().float() for k, v in V.random_state_dict(vcfg, seed=77).items()}
+    with torch.no_grad():
+        want = V.decode_latents(vsd, vcfg, lp["last"].float())[0].permute(1, 2, 3, 0).numpy()   # f h w c in [0, 1]
+    assert np.abs(frames.astype(np.float32) / 255.0 - want).max() < 0.03
+
+    # ---- prompt encoding: [negative_prompt, new_prompt] through the script's tokenizer + the drop-in text encoder -----
+    import transformers
+    tok = transformers.CLIPTokenizer.from_pretrained(os.path.join(str(tmp_path), "sd"), subfolder="tokenizer")
+    ids = tok(["bad quality", "a cat runs"], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    cc = EH.tiny_clip_config()
+    hc = transformers.CLIPTextConfig(**{k: cc[k] for k in cc}, attn_implementation="eager")
+    hf = transformers.CLIPTextModel(hc).eval()
+    wsd = torch.load(os.path.join(str(tmp_path), "sd", "text_encoder", "pytorch_model.bin"))
+    own = hf.state_dict()
+    if not any(k.startswith("text_model.") for k in own):
+        wsd = {k[len("text_model."):]: v for k, v in wsd.items()}
+    missing, unexpected = hf.load_state_dict(wsd, strict=False)
+    assert not unexpected and all(k.endswith("position_ids") for k in missing)
+    with torch.no_grad():
+        want_text = hf(ids)[0]
+    assert rel(lp["text"], want_text) < 1e-2
