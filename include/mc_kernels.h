@@ -29,6 +29,18 @@ extern "C" {
 #define MC_ABI_VERSION 1
 int mc_version(void);
 
+/* Workspace sizes in bytes (the caller owns every workspace; negative = bad arguments):
+ *   gemm_splitk          `ws` of mc_gemm_splitk_f16 (fp32 partial tiles, splits from mc_gemm_splitk_plan & 0xFF)
+ *   groupnorm            `partial` of mc_groupnorm_stats_f16 and mc_groupnorm_bwd_f16
+ *   groupnorm_bwd_stats  `bstats` of mc_groupnorm_bwd_f16
+ *   attn_bwd             `Dbuf` of mc_attn_bwd_f16
+ *   tattn_loss           `unit_loss` of mc_tattn_loss_f16 */
+long mc_workspace_bytes_gemm_splitk(int M, int N, int splits);
+long mc_workspace_bytes_groupnorm(int frames, int hw);
+long mc_workspace_bytes_groupnorm_bwd_stats(int frames);
+long mc_workspace_bytes_attn_bwd(int nbatch, int heads, int Nq);
+long mc_workspace_bytes_tattn_loss(int B, int HW, int heads);
+
 /* ---- MFMA GEMM / implicit convolution ------------------------------------------------------
  * C[M,N] = alpha * A[M,K] . W[N,K]^T + bias[m / rows_per_batch][n] + R[m][n]
  * mode 0 DENSE    : nn.Linear / 1x1 conv  (attention.py:65,93,355-357,364; motion_module.py:113,135;

@@ -34,7 +34,8 @@ def _run(cmd):
 
 
 def _deps():
-    return [os.path.join(CSRC, s) for s in SOURCES] + [os.path.join(CSRC, "mc_common.hpp"), os.path.join(CSRC, "gemm_params.hpp")]
+    import glob
+    return [os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp")))
 
 
 def build_hip(force=False, verbose=False):

@@ -411,6 +411,17 @@ extern "C" int mc_cfg_ddim_step_f16(const void* eps_c, const void* eps_u, int ld
 
 extern "C" int mc_version(void) { return 1; }
 
+// ---- workspace sizes (bytes) of the entry points that take a caller-owned workspace -----------------------------------
+extern "C" long mc_workspace_bytes_gemm_splitk(int M, int N, int splits) {
+    return (M <= 0 || N <= 0 || splits < 1) ? -1 : (long)sizeof(float) * splits * M * N;
+}
+extern "C" long mc_workspace_bytes_attn_bwd(int nbatch, int heads, int Nq) {
+    return (nbatch <= 0 || heads <= 0 || Nq <= 0) ? -1 : (long)sizeof(float) * nbatch * heads * Nq;
+}
+extern "C" long mc_workspace_bytes_tattn_loss(int B, int HW, int heads) {
+    return (B <= 0 || HW <= 0 || heads <= 0) ? -1 : (long)sizeof(float) * B * HW * heads;
+}
+
 extern "C" int mc_softmax_rows_f16(void* x, int ld, int rows, int cols, void* stream) {
     if (rows <= 0 || cols <= 0 || cols % 8 || ld % 8 || ld < cols) return MC_ERR_SHAPE;
     MC_LAUNCH(softmax_rows_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (half_t*)x, ld, cols);

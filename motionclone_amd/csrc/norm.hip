@@ -439,6 +439,14 @@ extern "C" int mc_gn_nchunk(int hw) {
     return n;
 }
 
+// bytes of the `partial` workspace of mc_groupnorm_stats_f16 / mc_groupnorm_bwd_f16, and of the latter's `bstats`
+extern "C" long mc_workspace_bytes_groupnorm(int frames, int hw) {
+    return (frames <= 0 || hw <= 0) ? -1 : (long)sizeof(float) * frames * mc_gn_nchunk(hw) * 64;
+}
+extern "C" long mc_workspace_bytes_groupnorm_bwd_stats(int frames) {
+    return frames <= 0 ? -1 : (long)sizeof(float) * frames * 64;
+}
+
 // workspace: float partial[frames * nchunk * 32 * 2]; output stats: float[frames*32*2] (mean, rstd)
 extern "C" int mc_groupnorm_stats_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot,
                                       int frames, int hw, float eps, float* partial, float* stats,

@@ -163,11 +163,25 @@ class Tape:
 
 
 class UNet3DEngine:
-    def __init__(self, state_dict, cfg=None, device="cuda", guidance_block=1, grad_scale=1024.0):
+    def __init__(self, state_dict, cfg=None, device="cuda", guidance_block=1, grad_scale=1024.0, guidance_blocks=None):
+        """guidance_blocks: input_config.motion_guidance_blocks (e.g. ['up_blocks.1']); a temporal attention is hooked when
+        its name contains one of the entries (util.py:434-440), and the up blocks up to the index of the LAST entry
+        stay in the differentiated half (motionclone_functions.py:602).  guidance_block = that index when no list is given."""
         self.cfg = dict(cfg or default_config())
         self.dev = torch.device(device)
         self.w = Weights(state_dict, self.cfg, self.dev)
-        self.guidance_block = guidance_block
+        if guidance_blocks is None:
+            guidance_blocks = ["up_blocks.%d" % guidance_block]
+        self.guidance_blocks = tuple(guidance_blocks)
+        self.guidance_block = int(self.guidance_blocks[-1].split(".")[-1])
+        for blk in self.guidance_blocks:
+            kind, _, idx = blk.partition(".")
+            if kind not in ("down_blocks", "up_blocks", "mid_block") or (kind == "up_blocks" and idx.split(".")[0].isdigit()
+                                                                         and int(idx.split(".")[0]) > self.guidance_block):
+                # an up block behind the last entry runs under no_grad and after the extraction's early return in the
+                # reference (:627-652): its recorded q / k would be stale there
+                raise NotImplementedError("motion_guidance_blocks entry %r cannot be honoured (last entry: %r)"
+                                          % (blk, self.guidance_blocks[-1]))
         self.grad_scale = float(grad_scale)
         self.G = self.cfg["norm_num_groups"]
         assert self.G == 32, "kernels are specialised for GroupNorm(32)"
@@ -506,7 +520,9 @@ class UNet3DEngine:
         text2d = text.reshape(B * n_text, text.shape[2]).contiguous()
         tb_all = self._time_bias(t, B, latents)
         gb = self.guidance_block
-        hooked = "up_blocks.%d" % gb
+
+        def hook(nm):   # classify_blocks (util.py:434-440): substring match against every configured block
+            return any(blk in nm for blk in self.guidance_blocks)
 
         x_in = ops.latent_to_cl(latents, CIN_PAD)
         x = ops.gemm(x_in, w.conv("conv_in.weight", CIN_PAD), bias=w.vec("conv_in.bias").unsqueeze(0), mode=CONV_S1,
@@ -529,7 +545,8 @@ class UNet3DEngine:
                 x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, tape)
                 if cfg["down_has_attn"][i]:
                     x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, tape)
-                x = self._motion("down_blocks.%d.motion_modules.%d" % (i, j), x, geo, tape, None, None)
+                nm = "down_blocks.%d.motion_modules.%d" % (i, j)
+                x = self._motion(nm, x, geo, tape, record if hook(nm) else None, seeds if hook(nm) else None)
                 skips.append((x, geo))
             if i < 3:
                 x, geo = self._downsample("down_blocks.%d.downsamplers.0.conv." % i, x, geo, tape)
@@ -564,7 +581,7 @@ class UNet3DEngine:
                 if cfg["up_has_attn"][i]:
                     x = self._spatial("up_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, tp)
                 nm = "up_blocks.%d.motion_modules.%d" % (i, j)
-                is_hooked = hooked in nm
+                is_hooked = in_graph and hook(nm)
                 x = self._motion(nm, x, geo, tp, record if is_hooked else None, seeds if is_hooked else None)
             if i < 3:
                 # the upsampler of block i feeds block i+1: in the graph only while i+1 <= guidance block
@@ -577,9 +594,12 @@ class UNet3DEngine:
 
     # ---- guidance layer -----------------------------------------------------------------------------------
     def hooked_names(self):
+        """names of the hooked temporal attentions in module order (= the keys of the reference's .pt dict)"""
         L = self.cfg["layers_per_block"]
-        return ["up_blocks.%d.motion_modules.%d.temporal_transformer.transformer_blocks.0.attention_blocks.%d"
-                % (self.guidance_block, j, a) for j in range(L + 1) for a in range(2)]
+        mods = ["down_blocks.%d.motion_modules.%d" % (i, j) for i in range(4) for j in range(L)]
+        mods += ["up_blocks.%d.motion_modules.%d" % (i, j) for i in range(self.guidance_block + 1) for j in range(L + 1)]
+        names = [m + ".temporal_transformer.transformer_blocks.0.attention_blocks.%d" % a for m in mods for a in range(2)]
+        return [n for n in names if any(blk in n for blk in self.guidance_blocks)]
 
     @ops.scoped
     def extract_representation(self, noisy_latents, t, uncond_text, down_residuals=None, mid_residual=None):

@@ -19,6 +19,11 @@ P, I, L, F = c_void_p, c_int, c_long, c_float
 # name -> argument ctypes, in the order of include/mc_kernels.h
 SIGNATURES = {
     "mc_version": [],
+    "mc_workspace_bytes_gemm_splitk": [I, I, I],
+    "mc_workspace_bytes_groupnorm": [I, I],
+    "mc_workspace_bytes_groupnorm_bwd_stats": [I],
+    "mc_workspace_bytes_attn_bwd": [I, I, I],
+    "mc_workspace_bytes_tattn_loss": [I, I, I],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
     "mc_gemm_splitk_plan": [I, I, I, I],
     "mc_softmax_rows_f16": [P, I, I, I, P],
@@ -69,7 +74,7 @@ def _bind(path):
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_long if name.startswith("mc_workspace_bytes_") else c_int
     return lib
 
 
@@ -98,6 +103,21 @@ def is_emulated():
 
 
 _FN = {}   # name -> bound ctypes function of the loaded library (cleared whenever the library changes)
+
+
+_WS = {}   # (op, dims) -> workspace bytes, memoised (one ctypes round trip per distinct shape)
+
+
+def workspace_bytes(op, *dims):
+    """mc_workspace_bytes_<op>(dims...) of the loaded library"""
+    key = (op, dims, _is_emulated)
+    n = _WS.get(key)
+    if n is None:
+        n = getattr(load() if _lib is None else _lib, "mc_workspace_bytes_" + op)(*dims)
+        if n < 0:
+            raise RuntimeError("mc_workspace_bytes_%s%r: bad arguments" % (op, dims))
+        _WS[key] = n
+    return n
 
 
 def call(name, *args):

@@ -114,6 +114,7 @@ class UNet3DConditionModel(nn.Module):
         self.input_config = None
         self._engine = None
         self._engine_key = None
+        self._weights_version = 0
 
     # ---- diffusers-style surface ----------------------------------------------------------------------
     @property
@@ -153,22 +154,28 @@ class UNet3DConditionModel(nn.Module):
     def load_state_dict(self, state_dict, strict=True, **kw):
         state_dict = {k: v for k, v in state_dict.items() if "pos_encoder.pe" not in k}
         out = super().load_state_dict(state_dict, strict=strict, **kw)
-        self._engine = None
+        self.invalidate_engine()
         return out
 
     # ---- execution --------------------------------------------------------------------------------------
     def engine(self):
         """The packed-weight execution engine for the current parameters/device (rebuilt after weight changes)."""
         p0 = next(self.parameters())
-        key = (p0.device, p0.data_ptr())
+        blocks = ("up_blocks.1",)
+        if self.input_config is not None:    # re-assigned per example by the entry scripts (t2v_video_sample.py:82)
+            blocks = tuple(self.input_config.motion_guidance_blocks)
+        key = (p0.device, p0.data_ptr(), blocks, self._weights_version)
         if self._engine is None or self._engine_key != key:
-            gb = 1
-            if self.input_config is not None:
-                gb = int(self.input_config.motion_guidance_blocks[-1].split(".")[-1])
             sd = {k: v for k, v in self.state_dict().items()}
-            self._engine = UNet3DEngine(sd, self.engine_config, p0.device, guidance_block=gb)
+            self._engine = UNet3DEngine(sd, self.engine_config, p0.device, guidance_blocks=blocks)
             self._engine_key = key
         return self._engine
+
+    def invalidate_engine(self):
+        """Call after editing parameters in place (e.g. `weight.data += ...`, as LoRA merges do): the engine packs fp16
+        copies of the weights lazily and would otherwise keep serving the old ones.  load_state_dict does this itself."""
+        self._weights_version += 1
+        self._engine = None
 
     def temporal_attentions(self):
         return [(n, m) for n, m in self.named_modules() if isinstance(m, VersatileAttention)]

@@ -66,6 +66,11 @@ def empty(shape, like, dtype=torch.float16):
     return torch.empty(shape, dtype=dtype, device=like.device)
 
 
+def workspace(op, like, *dims):
+    """caller-owned workspace of `op`, sized by the library's own mc_workspace_bytes_<op> (include/mc_kernels.h)"""
+    return torch.empty(lib.workspace_bytes(op, *dims) // 4, dtype=torch.float32, device=like.device)
+
+
 # ---- GEMM family ---------------------------------------------------------------------------------
 _SPLIT_PLAN = {}   # (M, N, K, mode) -> mc_gemm_splitk_plan, memoised: one ctypes round trip less per launch
 
@@ -111,7 +116,7 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
                 flags |= (splits >> 8) << 12
                 splits &= 0xFF
     if splits > 1:
-        ws = empty((splits * M * N,), a, torch.float32)
+        ws = workspace("gemm_splitk", a, M, N, splits)
         lib.call("mc_gemm_splitk_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
                  _ld(a2), _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha),
                  flags, _p(ws), splits, _stream(a))
@@ -139,8 +144,7 @@ def interleave_geglu(t):
 def gn_stats(x, x2, frames, hw, eps):
     c1 = x.shape[1]
     ctot = c1 + (x2.shape[1] if x2 is not None else 0)
-    nchunk = lib.load().mc_gn_nchunk(hw)
-    partial = empty((frames * nchunk * 64,), x, torch.float32)
+    partial = workspace("groupnorm", x, frames, hw)
     stats = empty((frames, 32, 2), x, torch.float32)
     lib.call("mc_groupnorm_stats_f16", _p(x), _p(x2), _ld(x), _ld(x2), c1, ctot, frames, hw, float(eps),
              _p(partial), _p(stats), _stream(x))
@@ -160,9 +164,8 @@ def gn_apply(x, x2, stats, gamma, beta, silu, frames, hw, out=None):
 def gn_bwd(x, x2, dz, stats, gamma, beta, silu, frames, hw, out=None, accumulate=False):
     c1 = x.shape[1]
     ctot = c1 + (x2.shape[1] if x2 is not None else 0)
-    nchunk = lib.load().mc_gn_nchunk(hw)
-    partial = empty((frames * nchunk * 64,), x, torch.float32)
-    bstats = empty((frames * 64,), x, torch.float32)
+    partial = workspace("groupnorm", x, frames, hw)
+    bstats = workspace("groupnorm_bwd_stats", x, frames)
     if out is None:
         assert not accumulate
         out = empty((frames * hw, ctot), x)
@@ -232,7 +235,7 @@ def quick_gelu(x):
 def attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nbatch, kv_bdiv=1, scale=None, dq=None, dk=None, dv=None,
              need_dkv=True):
     scale = d ** -0.5 if scale is None else scale
-    dbuf = empty((nbatch * heads * Nq,), q, torch.float32)
+    dbuf = workspace("attn_bwd", q, nbatch, heads, Nq)
     if dq is None:
         dq = empty((q.shape[0], heads * d), q)
     if need_dkv:
@@ -281,7 +284,7 @@ def tattn_loss(q, k, ref_idx, ref_val, B, F, HW, heads, d, scale=None):
     scale = d ** -0.5 if scale is None else scale
     assert ref_idx.dtype == torch.uint8 and ref_idx.is_contiguous()
     _f32(ref_val)
-    ul = empty((B * HW * heads,), q, torch.float32)
+    ul = workspace("tattn_loss", q, B, HW, heads)
     loss = empty((1,), q, torch.float32)
     lib.call("mc_tattn_loss_f16", _p(q), _p(k), _ld(q), _p(ref_idx), _p(ref_val), _p(ul), _p(loss), B, F, HW,
              heads, d, float(scale), _stream(q))
@@ -402,7 +405,9 @@ def silu(x):
 
 def cfg_ddim_step(eps_c, eps_u, x, score, cfg, a_t, a_prev, score_coef, want_eps=False):
     """x, score: [1, CL, F, H, W]; eps_*: channels-last token matrices (first CL columns)."""
-    _, CL, F, H, W = x.shape
+    B, CL, F, H, W = x.shape
+    if B != 1 or (score is not None and tuple(score.shape) != tuple(x.shape)):
+        raise ValueError("cfg_ddim_step updates one video per call: x %s, score %s" % (tuple(x.shape), None if score is None else tuple(score.shape)))
     x = x.contiguous()
     out = torch.empty_like(x)
     eps_out = torch.empty_like(x) if want_eps else None

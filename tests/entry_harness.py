@@ -161,7 +161,7 @@ def write_tokenizer(path):
     json.dump({"model_max_length": 77, "tokenizer_class": "CLIPTokenizer"}, open(os.path.join(path, "tokenizer_config.json"), "w"))
 
 
-def write_assets(work, kind):
+def write_assets(work, kind, n_examples=1):
     from motionclone_amd.models.clip import clip_param_shapes
     from oracle import unet3d_ref as U
     from oracle import vae_ref as V
@@ -233,6 +233,8 @@ def write_assets(work, kind):
     yaml.safe_dump(infer, open(os.path.join(work, "infer.yaml"), "w"))
     with open(os.path.join(work, "examples.jsonl"), "w") as f:
         f.write(json.dumps(example) + "\n")
+        for n in range(1, n_examples):     # same reference video (the .pt is overwritten per example, as in the reference)
+            f.write(json.dumps(dict(example, new_prompt="a dog walks %d" % n, seed=2026 + n)) + "\n")
     return cfg
 
 
@@ -271,7 +273,11 @@ def install_recorders(rec):
 
 
 def main():
+    """entry_harness.py KIND WORKDIR [--examples N] [--launch]   (--launch: through motionclone_amd.launch, sharded over the
+    torchrun environment's ranks; the assets must already exist in WORKDIR, outputs go to WORKDIR/rank<r>_*)"""
     kind, work = sys.argv[1], os.path.abspath(sys.argv[2])
+    n_examples = int(sys.argv[sys.argv.index("--examples") + 1]) if "--examples" in sys.argv else 1
+    launch = "--launch" in sys.argv
     os.makedirs(work, exist_ok=True)
     sys.path.insert(0, ROOT)        # `motionclone` must resolve to this repo's drop-in package, not to the reference's
     assert not any(os.path.abspath(p) == REFERENCE_ROOT for p in sys.path)
@@ -280,18 +286,28 @@ def main():
         lib.use_library_for_tests(build.build_emu())
         map_cuda_to_cpu()
     written = install_stubs(work)
-    write_assets(work, kind)
+    if not launch:
+        write_assets(work, kind, n_examples)
     rec = {}
     install_recorders(rec)
     script = os.path.join(REFERENCE_ROOT, "t2v_video_sample.py" if kind == "t2v" else "i2v_video_sample.py")
+    common = dict(pretrained_model_path=os.path.join(work, "sd"), inference_config=os.path.join(work, "infer.yaml"),
+                  examples=os.path.join(work, "examples.jsonl"))
+    if launch:
+        from motionclone_amd import launch as L
+        rank = int(os.environ.get("RANK", 0))
+        L.main([script, "--pretrained-model-path", common["pretrained_model_path"], "--inference_config",
+                common["inference_config"], "--examples", common["examples"], "--motion-representation-save-dir",
+                os.path.join(work, "mr_sharded"), "--generated-videos-save-dir", os.path.join(work, "videos_rank%d" % rank),
+                "--L", str(F), "--W", str(PX), "--H", str(PX), "--vae-scale", "2"])
+        print("ENTRY_OK", kind, written)
+        return
     ns = runpy.run_path(script, run_name="entry_script_under_test")
     import motionclone.models.unet as mu
     assert os.path.abspath(mu.__file__).startswith(ROOT), mu.__file__
-    args = argparse.Namespace(pretrained_model_path=os.path.join(work, "sd"), inference_config=os.path.join(work, "infer.yaml"),
-                              examples=os.path.join(work, "examples.jsonl"),
-                              motion_representation_save_dir=os.path.join(work, "motion_representation"),
+    args = argparse.Namespace(motion_representation_save_dir=os.path.join(work, "motion_representation"),
                               generated_videos_save_dir=os.path.join(work, "generated_videos"), visible_gpu=None,
-                              default_seed=2025, L=F, W=PX, H=PX, without_xformers=False)
+                              default_seed=2025, L=F, W=PX, H=PX, without_xformers=False, **common)
     ns["main"](args)
     rec["videos"] = written
     torch.save(rec, os.path.join(work, "record.pt"))

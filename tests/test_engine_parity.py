@@ -125,3 +125,39 @@ def test_forward_more_than_16_frames(backend, tiny):
     with torch.no_grad():
         ref = U.unet_forward(sd, cfg, lat.float(), 301, text.float())
     assert rel_err(ops.cl_to_latent(eps, 1, 4, 20, 8, 8).float().cpu(), ref) < 2e-2
+
+
+def test_multiple_guidance_blocks_match_oracle(backend, tiny):
+    """motion_guidance_blocks with more than one entry: every temporal attention whose name contains one of them is hooked
+    (util.py:434-440), the index of the LAST entry bounds the differentiated half (motionclone_functions.py:602)"""
+    dev = backend
+    cfg, sd = tiny
+    lat, text, vid, noise = make_inputs(cfg)
+    blocks = ["down_blocks.2", "up_blocks.1"]
+    eng = UNet3DEngine(sd, cfg, dev, guidance_blocks=blocks)
+    names = eng.hooked_names()
+    assert len(names) == 4 + 6 and names[0].startswith("down_blocks.2.motion_modules.0.")
+    smp = MotionCloneSampler(eng, num_inference_steps=4, guidance_steps=2, guidance_scale=0.3, **HP)
+    rep = smp.extract(vid.half().to(dev), noise.half().to(dev), text[[0]].half().to(dev))
+    noisy = smp.add_noise(400, vid.half(), noise.half()).float()
+    rec = {}
+    with torch.no_grad():
+        U.unet_forward(sd, cfg, noisy, 400, text[[0]].half().float(), only_motion_feature=True, record=rec, hooked=tuple(blocks))
+        ref = G.motion_representation(G.temp_attn_prob(rec, cfg["motion_heads"]))
+    assert list(rep) == list(ref) == names
+    for k in ref:
+        assert (rep[k][0].float().cpu() - ref[k][0]).abs().max() < 5e-3
+    # gradient of the 10-module loss
+    lat16, text16 = lat.half(), text.half()
+    t = int(smp.timesteps[0])
+    _, grad, loss = eng.guided_eps_and_grad(lat16.to(dev), t, text16[1:2].to(dev), eng.prepare_representation(ref), 2000.0,
+                                            want_loss=True)
+    control = lat16.float().clone().requires_grad_(True)
+    rec = {}
+    U.unet_forward(sd, cfg, control, t, text16[[1]].float(), record=rec, hooked=tuple(blocks))
+    ref_loss = 2000.0 * G.temp_loss(G.temp_attn_prob(rec, cfg["motion_heads"]), ref)
+    (ref_grad,) = torch.autograd.grad(ref_loss, control)
+    assert abs(float(loss) - float(ref_loss)) < 3e-2 * abs(float(ref_loss))
+    assert rel_err(grad, ref_grad) < 5e-2
+    with pytest.raises(NotImplementedError):
+        UNet3DEngine(sd, cfg, dev, guidance_blocks=["up_blocks.2", "up_blocks.1"])

@@ -32,24 +32,42 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
+N_EXAMPLES = {"t2v": 2, "i2v": 1}
+LAST = {"t2v": ("a dog walks 1", 2027), "i2v": ("a cat runs", 42)}
+
+
 def run_harness(kind, work):
     env = dict(os.environ, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), kind, str(work)],
-                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=str(work))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), kind, str(work), "--examples",
+                        str(N_EXAMPLES[kind])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=str(work))
     assert r.returncode == 0 and "ENTRY_OK" in r.stdout, r.stdout[-4000:]
     return torch.load(os.path.join(str(work), "record.pt"))
 
 
+@pytest.fixture(scope="module")
+def runs(tmp_path_factory):
+    cache = {}
+
+    def get(kind):
+        if kind not in cache:
+            work = tmp_path_factory.mktemp(kind)
+            cache[kind] = (work, run_harness(kind, work))
+        return cache[kind]
+    return get
+
+
 @pytest.mark.parametrize("kind", ["t2v", "i2v"])
-def test_unmodified_entry_script_matches_oracle(kind, tmp_path):
+def test_unmodified_entry_script_matches_oracle(kind, runs):
     import entry_harness as EH
-    rec = run_harness(kind, tmp_path)
+    tmp_path, rec = runs(kind)
     cfg = dict(U.TINY_CONFIG)
     sd = {k: v.half().float() for k, v in U.random_state_dict(cfg, seed=1234).items()}
     N, Gs, gs = EH.STEPS, EH.GUIDED, EH.GSCALE
 
     # quirk 2: the yaml key is `postive_prompt`, the script reads `positive_prompt` -> the suffix is never appended
-    assert [os.path.basename(p) for p in rec["videos"]] == ["clip_a_cat_runs42_42.mp4"]
+    want_names = ["clip_a_cat_runs42_42.mp4"] + ["clip_a_dog_walks_%d%d_%d.mp4" % (n, 2026 + n, 2026 + n)
+                                                 for n in range(1, N_EXAMPLES[kind])]
+    assert [os.path.basename(p) for p in rec["videos"]] == want_names
 
     # ---- the .pt written by the script and loaded back by sample_video ------------------------------------------------
     pt = torch.load(os.path.join(str(tmp_path), "motion_representation", "clip.pt"))
@@ -107,7 +125,7 @@ def test_unmodified_entry_script_matches_oracle(kind, tmp_path):
     assert rel(lp["last"], x) < 3e-2, rel(lp["last"], x)
 
     # ---- decoded video handed to imageio.mimwrite --------------------------------------------------------------------
-    frames = np.load(rec["videos"][0] + ".npy")
+    frames = np.load(rec["videos"][-1] + ".npy")    # the records are those of the last example
     assert frames.dtype == np.uint8 and frames.shape == (EH.F, EH.PX, EH.PX, 3)
     vcfg = dict(V.TINY_VAE_CONFIG)
     vsd = {k: v.half().float() for k, v in V.random_state_dict(vcfg, seed=77).items()}
@@ -118,7 +136,7 @@ def test_unmodified_entry_script_matches_oracle(kind, tmp_path):
     # ---- prompt encoding: [negative_prompt, new_prompt] through the script's tokenizer + the drop-in text encoder -----
     import transformers
     tok = transformers.CLIPTokenizer.from_pretrained(os.path.join(str(tmp_path), "sd"), subfolder="tokenizer")
-    ids = tok(["bad quality", "a cat runs"], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
+    ids = tok(["bad quality", LAST[kind][0]], padding="max_length", max_length=77, truncation=True, return_tensors="pt").input_ids
     cc = EH.tiny_clip_config()
     hc = transformers.CLIPTextConfig(**{k: cc[k] for k in cc}, attn_implementation="eager")
     hf = transformers.CLIPTextModel(hc).eval()
@@ -131,3 +149,33 @@ def test_unmodified_entry_script_matches_oracle(kind, tmp_path):
     with torch.no_grad():
         want_text = hf(ids)[0]
     assert rel(lp["text"], want_text) < 1e-2
+
+
+def test_launcher_shards_examples_and_reproduces_the_serial_run(runs):
+    """motionclone_amd.launch under a 2-rank torchrun environment (gloo): rank r runs the unmodified script on lines
+    r, r+2, ...; with the serial-RNG burn the sharded videos are bit-identical to the single-process run (quirk 10)"""
+    import socket
+    work, rec = runs("t2v")
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), "t2v", str(work),
+                                       "--launch"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env,
+                                      cwd=str(work)))
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ENTRY_OK" in o, o[-4000:]
+    assert '"world": 2' in outs[0] and '"examples": 2' in outs[0]
+    serial = [np.load(v + ".npy") for v in rec["videos"]]
+    for r in range(2):
+        name = os.path.basename(rec["videos"][r])
+        got = np.load(os.path.join(str(work), "videos_rank%d" % r, name + ".npy"))
+        assert np.array_equal(got, serial[r]), "rank %d video differs from the serial run" % r
+        assert os.path.exists(os.path.join(str(work), "mr_sharded", "rank%d" % r, "clip.pt"))
+        other = os.path.join(str(work), "videos_rank%d" % r, os.path.basename(rec["videos"][1 - r]) + ".npy")
+        assert not os.path.exists(other)      # every example ran exactly once
