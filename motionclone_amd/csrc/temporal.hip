@@ -144,20 +144,47 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
         f32x4 st[NT];
         t_scores_T<NT, DT>(P, u, tq, lane, st);
         const int qf = 16 * tq + (lane & 15);
-        if (mode == 1) {
-            // arg-max over raw scores (lowest index wins ties), value = 1 / sum exp(s - max)
-            float best = -INFINITY;
+        if (mode == 1 || mode == 3) {
+            // The reference's order of operations in its own (fp16) arithmetic (attention.py:593-609,
+            // motionclone_functions.py:79): scores leave baddbmm ROUNDED TO fp16 (fp32 accumulate, alpha = scale applied
+            // before the rounding); softmax is evaluated in fp32 on those fp16 scores - exp(s - max) / sum, a true
+            // division - and ROUNDED TO fp16; topk(k = 1) then runs on the fp16 probabilities, so distinct scores whose
+            // probabilities round to the same fp16 value are ties.  Ties go to the lowest index.
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) st[tk][i] = (float)(half_t)st[tk][i];   // -inf (masked kv) stays -inf
+            float m = -INFINITY;
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) m = fmaxf(m, st[tk][i]);
+            m = group_max(m);
+            float l = 0.f;
+#pragma unroll
+            for (int tk = 0; tk < NT; ++tk)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    st[tk][i] = expf(st[tk][i] - m);
+                    l += st[tk][i];
+                }
+            l = group_sum(l);
+            float best = -1.f;
             int bi = 0;
 #pragma unroll
             for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     int kv = 16 * tk + 4 * (lane >> 4) + i;
-                    if (st[tk][i] > best) {
-                        best = st[tk][i];
+                    half_t ph = (half_t)(st[tk][i] / l);
+                    if (mode == 3) {
+                        if (qf < P.F && kv < P.F) top_val[(unit * P.F + qf) * P.F + kv] = ph;
+                    } else if (kv < P.F && (float)ph > best) {   // ascending kv within the lane: first maximum kept
+                        best = (float)ph;
                         bi = kv;
                     }
                 }
+            if (mode == 3) continue;
 #pragma unroll
             for (int msk = 16; msk <= 32; msk <<= 1) {
                 float ob = shfl_xor(best, msk);
@@ -167,10 +194,8 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
                     bi = oi;
                 }
             }
-            float m, l;
-            t_softmax_T<NT>(st, m, l);
             if (lane < 16 && qf < P.F) {
-                top_val[unit * P.F + qf] = (half_t)(1.0f / l);
+                top_val[unit * P.F + qf] = (half_t)best;
                 top_idx[unit * P.F + qf] = (uint8_t)bi;
             }
             continue;
@@ -178,18 +203,6 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
         float m, l;
         t_softmax_T<NT>(st, m, l);
         const float inv = 1.0f / l;
-        if (mode == 3) {  // full probabilities P[unit][q][kv] (fp16), as get_temp_attn_prob returns them
-            if (qf < P.F) {
-#pragma unroll
-                for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int kv = 16 * tk + 4 * (lane >> 4) + i;
-                        if (kv < P.F) top_val[(unit * P.F + qf) * P.F + kv] = (half_t)(st[tk][i] * inv);
-                    }
-            }
-            continue;
-        }
         if (mode == 2) {
             int idx = qf < P.F ? (int)ref_idx[unit * P.F + qf] : 0;
             float pv = 0.f;
