@@ -38,6 +38,8 @@ def gemm_kernel_name(mode, M, N, K=0):
     modes = {ops.DENSE: "DENSE", ops.CONV_S1: "CONV_S1", ops.CONV_S2: "CONV_S2", ops.CONV_UP: "CONV_UP",
              ops.TCONV_S2: "TCONV_S2"}
     plan = lib.load().mc_gemm_splitk_plan(M, N, K, mode) if K else 1
+    if mode == ops.DENSE and K == 320 and N % 32 == 0 and (M >= 98304 or (M >= 32768 and N >= 640)):
+        return "gemm4_kernel<K=320 streaming>"
     if plan > 1:
         return "gemm3_kernel<%s,%s> split-K + reduce" % (modes[mode], "256,320,4,2" if (plan >> 8) == 1 else "128,320,2,2")
     if N % 320 == 0:
@@ -161,37 +163,104 @@ def vae_extras(dev, latents_tokens_or_lat, frames, size):
                 note="diffusers 0.16.0 AutoencoderKL architecture, synthetic weights; not part of `value`")
 
 
-def cpu_baseline():
-    """The oracle (CPU restatement of the reference path, oracle/unet3d_ref.py) timed on this box's host cores on a
-    bounded sample: one B=1 fp32 UNet3D forward of the full SD1.5+AnimateDiff architecture at 16f x 256x256, its
-    algorithmic FLOPs counted by torch's FlopCounterMode on the run itself, scaled to a config-2 video (1253 TFLOP).
-    Thread count is capped: with every hardware thread of a large host the small per-frame ops oversubscribe and
-    the forward gets >10x slower."""
-    from torch.utils.flop_counter import FlopCounterMode
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(budget_s=75.0):
+    """The oracle (CPU restatement of the reference path, oracle/unet3d_ref.py + guidance_ref.py, pinned to the unmodified
+    reference by tests/test_oracle_pins.py) timed on this box's host cores, fp32, full SD1.5+AnimateDiff architecture, seeded
+    synthetic weights, at BASELINE config 1's shape (16 f x 256 x 256, schedule (10, 5, 0.3)) as SURVEY.md 8(d) asks:
+    extraction, plain step (one B=2 forward) and guided step (two forwards + autograd backward) are timed SEPARATELY after
+    a warm-up forward, as many repetitions as a bounded time budget allows (median reported), and videos/min derived as
+    extraction + 5 guided + 5 plain.  The FLOP-scaled config-2 figure is kept as a cross-check."""
+    from oracle import guidance_ref as G
     from oracle import unet3d_ref as U
-    cores = min(32, os.cpu_count() or 1)
+    cores = min(32, os.cpu_count() or 1)   # more threads oversubscribe the small per-frame ops (measured: >10x slower)
     torch.set_num_threads(cores)
     cfg = U.SD15_CONFIG
-    sd = {}
-    for name, shape in U.param_shapes(cfg).items():  # cheap constant fill: values do not affect the timing
-        sd[name] = torch.full(shape, 0.01) if len(shape) > 1 else torch.full(shape, 1.0 if name.endswith("weight") else 0.0)
-    g = torch.Generator().manual_seed(1234)
-    lat = torch.randn(1, 4, 16, 32, 32, generator=g)
-    text = torch.randn(1, 77, 768, generator=g)
+    sd = U.random_state_dict(cfg, seed=1234)
+    F, H = 16, 32
+    g = lambda s: torch.Generator().manual_seed(s)   # noqa: E731
+    lat = torch.randn(1, 4, F, H, H, generator=g(2025))
+    text = torch.randn(2, 77, 768, generator=g(7))
+    vid = 0.18215 * torch.randn(1, 4, F, H, H, generator=g(11))
+    noise = torch.randn(1, 4, F, H, H, generator=g(2025))
+    ts = G.uneven_timesteps(10, 5, 0.3)
+    hp = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10, guidance_steps=5)
+    t_start = time.time()
     with torch.no_grad():
-        U.unet_forward(sd, cfg, lat[:, :, :2, :8, :8].contiguous(), 500, text)  # page in / thread-pool warm-up
-        fc = FlopCounterMode(display=False)
-        t0 = time.time()
-        with fc:
-            U.unet_forward(sd, cfg, lat, 500, text)
-        dt = time.time() - t0
-    tflop_sample = fc.get_total_flops() / 1e12
-    tflop_video = 18 * TFLOP_GUIDED + 12 * TFLOP_PLAIN + TFLOP_EXTRACT
-    sec_video = dt * tflop_video / tflop_sample
-    return dict(value=60.0 / sec_video, unit="videos/min", cores=cores, kind="port",
-                sample="oracle fp32 UNet3D forward, B=1, 16f x 256x256 (%.3f TFLOP counted) in %.1f s on %d threads; "
-                       "scaled by algorithmic FLOPs to one config-2 video (%.0f TFLOP)" % (tflop_sample, dt, cores, tflop_video),
-                sample_seconds=dt, tflops=tflop_sample / dt)
+        U.unet_forward(sd, cfg, lat[:, :, :2, :8, :8].contiguous(), 500, text[:1])   # page in / thread-pool warm-up
+
+    def timed(fn, max_reps=3):
+        ts_ = []
+        for _ in range(max_reps):
+            t0 = time.time()
+            out = fn()
+            ts_.append(time.time() - t0)
+            if time.time() - t_start > budget_s:
+                break
+        return sorted(ts_)[len(ts_) // 2], len(ts_), out
+    t_ext, n_ext, rep = timed(lambda: G.extract_representation(sd, cfg, vid, noise, text[0:1]))
+    t_plain, n_plain, _ = timed(lambda: G.plain_step_full(sd, cfg, lat, 5, ts, text, 7.5))
+    t_guided, n_guided, _ = timed(lambda: G.guided_step(sd, cfg, lat, 0, ts, text, rep, hp))
+    sec_cfg1 = t_ext + 5 * t_guided + 5 * t_plain
+    tflop_cfg1 = 2.39 + 5 * 10.41 + 5 * 8.17
+    tflop_cfg2 = 18 * TFLOP_GUIDED + 12 * TFLOP_PLAIN + TFLOP_EXTRACT
+    return dict(value=60.0 / sec_cfg1, unit="videos/min (BASELINE config 1: 16f x 256x256, schedule (10,5,0.3), UNet only)",
+                cores=cores, cpu_model=_cpu_model(), kind="port",
+                sample="oracle fp32 on %d threads, 16f x 256x256: extraction %.2f s (median of %d), plain step %.2f s (%d), "
+                       "guided step %.2f s (%d); one video = extraction + 5 guided + 5 plain = %.1f s"
+                       % (cores, t_ext, n_ext, t_plain, n_plain, t_guided, n_guided, sec_cfg1),
+                extraction_s=t_ext, plain_step_s=t_plain, guided_step_s=t_guided, sec_per_video_config1=sec_cfg1,
+                tflops=tflop_cfg1 / sec_cfg1,
+                config2_videos_per_min_flop_scaled=60.0 / (sec_cfg1 * tflop_cfg2 / tflop_cfg1))
+
+
+def reference_gpu_baseline(dev, size=512, sched=(30, 18, 0.4)):
+    """SURVEY.md 8(d) "before" number: the reference's arithmetic (the oracle = the same torch ops as the reference's modules)
+    on this MI355X through stock PyTorch-ROCm in fp16 (t2v_video_sample.py:19), without xformers (unavailable on ROCm):
+    guided step, plain step and extraction, median of 3 after a warm-up.  Convolutions use PyTorch's own GPU path (MIOpen
+    off: a fresh box has no precompiled gfx950 MIOpen kernels and would JIT every shape)."""
+    from oracle import guidance_ref as G
+    cfg = default_config()
+    sd, _ = spec.synthetic_state_dict(cfg, seed=1234, device=dev)
+    F, H = 16, size // 8
+    g = lambda s: torch.Generator(device=dev).manual_seed(s)   # noqa: E731
+    lat = torch.randn((1, 4, F, H, H), generator=g(2025), device=dev).half()
+    text = torch.randn((2, 77, 768), generator=g(7), device=dev).half()
+    vid = (0.18215 * torch.randn((1, 4, F, H, H), generator=g(11), device=dev)).half()
+    noise = torch.randn((1, 4, F, H, H), generator=g(2025), device=dev).half()
+    N, Gs, gs = sched
+    ts = G.uneven_timesteps(N, Gs, gs)
+    hp = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10, guidance_steps=Gs)
+
+    def med3(fn):
+        fn()
+        torch.cuda.synchronize()
+        ts_ = []
+        for _ in range(3):
+            t0 = time.perf_counter()
+            fn()
+            torch.cuda.synchronize()
+            ts_.append(time.perf_counter() - t0)
+        return sorted(ts_)[1]
+    with torch.backends.cudnn.flags(enabled=False, benchmark=False):
+        rep = G.extract_representation(sd, cfg, vid, noise, text[0:1])
+        t_ext = med3(lambda: G.extract_representation(sd, cfg, vid, noise, text[0:1]))
+        t_guided = med3(lambda: G.guided_step(sd, cfg, lat, 0, ts, text, rep, hp))
+        t_plain = med3(lambda: G.plain_step_full(sd, cfg, lat, Gs, ts, text, 7.5))
+    sec = t_ext + Gs * t_guided + (N - Gs) * t_plain
+    torch.cuda.empty_cache()
+    return dict(videos_per_min=60.0 / sec, sec_per_video=sec, extraction_s=t_ext, guided_step_s=t_guided, plain_step_s=t_plain,
+                dtype="f16", note="oracle (reference arithmetic) via stock PyTorch %s ROCm on %s, MIOpen off, no xformers; "
+                                  "config-2 shape, schedule %s" % (torch.__version__, torch.cuda.get_device_name(0), list(sched)))
 
 
 def main():
@@ -206,7 +275,7 @@ def main():
     ap.add_argument("--guided-steps", type=int, default=18)
     ap.add_argument("--guidance-scale", type=float, default=0.4)
     ap.add_argument("--sparsectrl", action="store_true", help="BASELINE config 4: add the SparseCtrl (i2v_rgb) encoder pass")
-    ap.add_argument("--no-graphs", action="store_true", help="skip the (untimed, informational) hipGraph replay measurement")
+    ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     args = ap.parse_args()
 
@@ -255,15 +324,20 @@ def main():
         mask[:, :, 0] = 1
         ctrl = dict(cond=cond, mask=mask, scale=1.0)
 
+    # The timed path replays one hipGraph per DDIM step (sampler.enable_graphs: bit-identical to the eager launches,
+    # tests/test_fullsize_properties.py); everything that differs between videos enters through static buffers.  The
+    # motion-representation extraction (once per video) stays eager.  `--no-graphs` times the eager launch sequence instead.
     probe = GemmProbe()
     probe.install()
-    for _ in range(args.warmup):
+    use_graphs = not args.no_graphs
+    if use_graphs:
+        smp.enable_graphs()
+    for _ in range(max(1, args.warmup) if use_graphs else args.warmup):   # the first graph pass captures: never timed
         out = one_video(smp, lat, text, vid, noise, ctrl=ctrl)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
-    probe.enabled = True
     step_events = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -273,38 +347,38 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    probe.enabled = False
     assert torch.isfinite(out.float()).all(), "non-finite latents"
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
-    # hipGraph replay of the same videos (sampler.enable_graphs), measured after and outside the timed region: the
-    # contract's `value` stays on the eager path, whose GEMM launches carry the HIP events of the roofline object
-    graph_info = None
-    if rank == 0 and world == 1 and not args.no_graphs:   # single-GPU runs only: the scaling runs stay minimal
-        smg = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
-                                 num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE,
-                                 controlnet=ceng).enable_graphs()
-        rep_dev = eng.prepare_representation(smg.extract(vid, noise, text[0:1], add_noise_step=400, ctrl=ctrl))
-
-        def loop():
-            x = lat
-            for i in range(len(smg.timesteps)):
-                x = smg.step(x, i, text, rep_dev, ctrl=ctrl)
-            return x
-        g_first = loop()                       # eager + capture
+    # Roofline probe: ONE more video on the eager launch sequence (same kernels, same order as the graphs hold), every GEMM /
+    # conv launch bracketed by HIP events on the launch stream.  Outside the timed region: events cannot bracket launches
+    # inside a graph replay.  `eager` also reports what the un-graphed loop costs on this box.
+    eager_info = None
+    probe_elapsed = None
+    if rank == 0:
+        sme = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
+                                 num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng)
+        out_e = one_video(sme, lat, text, vid, noise, ctrl=ctrl)      # untimed eager warm-up
         torch.cuda.synchronize()
-        tg0 = time.perf_counter()
-        for _ in range(args.steps):
-            smg.extract(vid, noise, text[0:1], add_noise_step=400, ctrl=ctrl)   # extraction stays eager (once per video)
-            g_out = loop()
+        te0 = time.perf_counter()
+        out_e = one_video(sme, lat, text, vid, noise, ctrl=ctrl)
         torch.cuda.synchronize()
-        tg = (time.perf_counter() - tg0) / args.steps
-        graph_info = dict(videos_per_min=60.0 / tg, sec_per_video=tg, identical_to_eager=bool(torch.equal(g_out, g_first)),
-                          note="30 captured step graphs replayed; extraction eager; not part of `value`")
-        del smg
+        te = time.perf_counter() - te0
+        probe.enabled = True
+        tp0 = time.perf_counter()
+        one_video(sme, lat, text, vid, noise, ctrl=ctrl)
+        torch.cuda.synchronize()
+        probe_elapsed = time.perf_counter() - tp0
+        probe.enabled = False
+        eager_info = dict(videos_per_min=60.0 / te, sec_per_video=te, identical_to_graph_path=bool(torch.equal(out_e, out)),
+                          note="same launch sequence without hipGraphs, one video; not part of `value`")
+        del sme
+    graph_info = dict(enabled=use_graphs, graphs=len(smp._graphs) if use_graphs else 0,
+                      note="one graph per DDIM step, captured during warm-up; latents / text / representation refreshed by "
+                           "device copies into static buffers before each replay; extraction eager")
     vae_info = None
     if rank == 0 and world == 1 and not args.no_vae:
         vae_info = vae_extras(dev, out, args.frames, args.size)
@@ -329,7 +403,7 @@ def main():
                                       avg_launch_us=g["avg_us"], flop_per_launch=g["flop"] / g["launches"],
                                       algorithmic_bytes_per_launch=g["bytes"] / g["launches"],
                                       algorithmic_gbps=g["alg_gbps"], traffic=traffic_tab.get(name),
-                                      share_of_timed_region=(g["ms"] / 1e3 / elapsed) if world == 1 else None)
+                                      share_of_probe_video=(g["ms"] / 1e3 / probe_elapsed))
             dom = max(groups, key=lambda n: groups[n]["ms"])   # dominant by time inside the timed region
             roof = dict(roof_all[dom], kernel=dom)
         res = {
@@ -350,13 +424,20 @@ def main():
             "e2e_tflops_per_gpu": tflop_video * args.steps / elapsed,
             "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
             "roofline": roof,
+            "roofline_note": "per-launch HIP events from ONE eager video run after the timed region (events cannot bracket "
+                             "launches inside a graph replay); `traffic` = PMC HBM bytes per launch of probe shapes "
+                             "(profiles/, tools/pmc_probe.py), null where not collected",
             "roofline_by_kernel": roof_all,
             # SURVEY.md 8(f) rank 1, measured OUTSIDE the timed region (BASELINE's metric is the UNet loop): the VAE calls
             # around it - decode_latents of the sampled video and the encode of the reference video - on the same kernels
             "vae": vae_info,
-            "graph_replay": graph_info,
+            "graphs": graph_info,
+            "eager": eager_info,
         }
         if world == 1 and not args.no_cpu_baseline:
+            del eng, smp
+            torch.cuda.empty_cache()
+            res["reference_gpu_baseline"] = reference_gpu_baseline(dev) if (args.frames, args.size) == (16, 512) else None
             res["cpu_baseline"] = cpu_baseline()
         else:
             res["cpu_baseline"] = None

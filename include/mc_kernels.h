@@ -61,6 +61,11 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
 
+/* PROFILING ONLY: timing experiments that drop parts of the GEMM kernels (1 = no global stores, 2 = no MFMA loop,
+ * 4 = no epilogue, 8 = no operand staging); outputs are garbage while set.  0 restores normal operation. */
+int mc_gemm_debug(int bits);
+int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
+
 /* Split-K variant for small-M / deep-K problems (the 8x8 and 16x16-level 3x3 convs of unet_blocks.py:Downsample3D /
  * ResnetBlock3D at reference motionclone/models/resnet.py:110-209): K is cut into `splits` ranges computed by
  * separate workgroups into the fp32 workspace ws[splits][M][N]; a reduce kernel applies bias / residual.

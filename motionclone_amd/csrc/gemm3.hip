@@ -315,10 +315,6 @@ static int launch3_cfg(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t 
         case 3: return launch3<MODE, 256, 128, 4, 2, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // wave 64 x 64
         case 4: return launch3<MODE, 128, 320, 2, 2, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // 4 waves, wave 64 x 160
         case 5: return launch3<MODE, 128, 256, 2, 4, 64, 2, 1, 2>(p, bA, bA2, bW, s);   // wave 64 x 64
-        case 6: return launch3<MODE, 128, 320, 2, 2, 32, 1, 2, 2>(p, bA, bA2, bW, s);   // 4 waves, K depth 32: 2 blocks / CU
-        case 7: return launch3<MODE, 256, 320, 4, 2, 32, 2, 1, 4>(p, bA, bA2, bW, s);   // cfg 1 as a 4-stage ring of K-32 tiles
-        case 8: return launch3<MODE, 128, 320, 2, 2, 32, 1, 2, 3>(p, bA, bA2, bW, s);   // cfg 6 with a 3-stage ring (84 KiB: 1 block / CU)
-        case 9: return launch3<MODE, 256, 256, 4, 2, 32, 2, 1, 4>(p, bA, bA2, bW, s);   // cfg 2 as a 4-stage ring
         default: return MC_ERR_UNSUPPORTED;
     }
 }

@@ -1,0 +1,321 @@
+// Streaming GEMM for the short-K Linear layers of the 64x64 level (K = 320: proj_in / proj_out, to_q|k|v, to_out,
+// FeedForward's first Linear; reference attention.py:65,93,355-364, motion_module.py:113,135, diffusers FeedForward).
+//
+// Why a second structure: with K = 320 a 256x320 output tile of the tiled kernel (gemm3.hip) is only five k-steps; its
+// prologue (cold operand fetch), the fp32 staged epilogue and the store tail take 4-5x the MFMA time of the tile, and
+// with one 8-wave workgroup per CU nothing else runs meanwhile (measured: 350-550 TFLOP/s, 22 % MFMA utilisation).
+// These layers are really streaming problems: A [M, 320] is read once, C [M, N] written once, W [N, 320] is tiny.
+//
+// Structure (one workgroup = 4 waves, 256 rows of A, two workgroups per CU):
+//   * A-stationary in REGISTERS: a wave owns 64 rows; their MFMA B-operand fragments for the whole K (2 x K/16 x 16 B per
+//     lane = 160 VGPRs at K = 320) are fetched once (global -> LDS by LDS-DMA in full lines, then ds_read_b128) and stay
+//     in registers for the sweep over N.  No A traffic, no A staging instructions in the main loop.
+//   * W streams through a 2-deep LDS ring in chunks of 32 output columns x K (20 KiB): 5 LDS-DMA instructions per wave per
+//     chunk, one workgroup barrier per chunk, 40 MFMAs (v_mfma_f32_32x32x16_f16) + 20 ds_read_b128 per wave per chunk.
+//   * the epilogue of a chunk is wave-private: accumulators -> fp16 -> the wave's own LDS staging rows -> read back as
+//     16 rows x 64 B per instruction (+ the residual, which arrives through LDS-DMA as well) -> buffer stores.  No
+//     barrier, no fp32 staging; the other workgroup on the CU computes meanwhile.
+//   * bias: the accumulators START as the bias (a 1 KiB LDS-DMA per 8 chunks, ds_read_b128 broadcast), no epilogue add.
+// Vector-memory counter discipline: per chunk a wave issues [W(c+2) x5][bias][R(c+1) x4][stores(c) x4] in that order, and
+// waits with `vmcnt <= 4` after the next chunk's MFMAs: everything but those four stores has retired (CDNA4 counts stores
+// in vmcnt and retires in order), so no wait ever has a store of the chunk in flight in front of it.
+#include "gemm_params.hpp"
+
+namespace mc {
+
+constexpr int G4_BM = 256;          // rows per workgroup
+constexpr int G4_BN = 32;           // output columns per chunk
+constexpr int G4_WRING = 0;         // LDS map (bytes): W ring 2 x KS/4 x 4 KiB
+
+template <int KS>
+struct G4Lds {
+    static constexpr int wchunk = (KS / 4) * 4096;       // [k-tile of 64][32 rows][128 B]
+    static constexpr int land = 2 * wchunk;              // A landing ring: 2 x [256 rows][64 B]   (dead after the A phase)
+    static constexpr int stg = land;                     // staging: 4 waves x [64 rows][128 B]    (same bytes as the landing ring)
+    static constexpr int bias = stg + 4 * 8192;          // 2 x 1 KiB (256 floats = 8 chunks each)
+    static constexpr int total = bias + 2048;
+    static_assert(land + 2 * 16384 <= bias, "landing ring must end before the bias ring");
+};
+
+// Staging row of a wave: 128 B = the output columns of one STORE GROUP (plain: 2 chunks x 32 columns; GEGLU: 4 chunks x
+// 16), as 8 slots of 16 B, slot s at physical slot s ^ ((row >> 1) & 7).  The image is lane-linear per 8 rows, so the
+// residual rows of the group are DMA'd straight into it (the swizzle goes on the source address) and the accumulators are
+// added IN PLACE; the group then leaves as whole 128-byte lines, 8 rows per store instruction.  Bank behaviour: the
+// in-place 8-byte accesses are 2-way (the minimum for 32 rows x 8 B), the 16-byte read-back is conflict-free.
+__device__ __forceinline__ int g4_stg_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int KS, bool GEGLU>
+__global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesW, uint32_t bytesC,
+                                                        uint32_t bytesR, uint32_t bytesB, int tilesM, int nsplit,
+                                                        int chunks) {
+    using L = G4Lds<KS>;
+    constexpr int KT = KS / 4;          // 64-wide k-tiles of a W chunk
+    constexpr int NT = KS / 2;          // 32-wide landing tiles of A
+    MC_DYN_SMEM(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int pid = blockIdx.x;
+    const int xcd = pid & 7, local = pid >> 3;
+    const int ns = local % nsplit;
+    const int tm = (local / nsplit) * 8 + xcd;
+    if (tm >= tilesM) return;
+    const int m0 = tm * G4_BM;
+    const int c_begin = ns * chunks;                                    // first chunk of this workgroup's N range
+    const int nchunks = min(chunks, p.N / G4_BN - c_begin);
+    if (nchunks <= 0) return;
+
+    const GBuf bufA = make_gbuf(p.A, bytesA);
+    const GBuf bufW = make_gbuf(p.W, bytesW);
+    const GBuf bufC = make_gbuf(p.C, bytesC);
+    const GBuf bufR = make_gbuf(p.R ? (const void*)p.R : (const void*)p.C, p.R ? bytesR : 0u);
+    const GBuf bufB = make_gbuf(p.bias ? (const void*)p.bias : (const void*)p.W, p.bias ? bytesB : 0u);
+    char* const sW = smem + G4_WRING;
+    char* const sLand = smem + L::land;
+    char* const sStg = smem + L::stg + wave * 8192;
+    char* const sBias = smem + L::bias;
+
+    // ---- issue helpers ------------------------------------------------------------------------------------------------
+    // W chunk c (absolute chunk index): this wave moves rows 8*wave .. +8 of every 64-wide k-tile
+    const int wrow = 8 * wave + (lane >> 3);
+    const int wslot = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);
+    auto issue_w = [&](int c, int buf) {
+        const int n = c * G4_BN + wrow;
+        const uint32_t base = n < p.N ? ((uint32_t)n * (uint32_t)p.K + (uint32_t)wslot * 8u) * 2u : kOOB;
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+            glds16(bufW, base == kOOB ? kOOB : base + (uint32_t)kt * 128u, sW + buf * L::wchunk + kt * 4096 + wave * 1024);
+    };
+    // residual rows of the store group starting at output column col0 (64 columns): 64 rows x 128 B into the staging image
+    auto issue_r = [&](int col0, int lane) {
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+            const int row = 8 * it + (lane >> 3);
+            const int m = m0 + 64 * wave + row;
+            const int lslot = (lane & 7) ^ ((row >> 1) & 7);
+            const int col = col0 + lslot * 8;
+            const uint32_t voff = (m < p.M && col < p.N) ? ((uint32_t)m * (uint32_t)p.ldr + (uint32_t)col) * 2u : kOOB;
+            glds16(bufR, voff, sStg + it * 1024);
+        }
+    };
+    // bias of 8 chunks (256 floats) starting at chunk group g of this workgroup's range
+    auto issue_bias = [&](int g) {
+        const uint32_t f = (uint32_t)((c_begin + 8 * g) * G4_BN + lane * 4);
+        glds16(bufB, f < (uint32_t)p.N ? f * 4u : kOOB, sBias + (g & 1) * 1024);
+    };
+
+    // ---- A phase: the wave's 64 rows x K as MFMA B-operand fragments, resident for the whole sweep --------------------------
+    half8_t a[2][KS];
+    {
+        if (wave == 0 && p.bias) issue_bias(0);
+        issue_w(c_begin, 0);
+        if (nchunks > 1) issue_w(c_begin + 1, 1);
+        const int lslot = (lane & 3) ^ ((lane >> 4) & 3);
+        auto issue_a = [&](int kt, int buf) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int g = wave + 4 * i;
+                const int m = m0 + 16 * g + (lane >> 2);
+                const uint32_t voff = m < p.M ? ((uint32_t)m * (uint32_t)p.lda + (uint32_t)(kt * 32 + lslot * 8)) * 2u : kOOB;
+                glds16(bufA, voff, sLand + buf * 16384 + g * 1024);
+            }
+        };
+        issue_a(0, 0);
+        if (NT > 1) issue_a(1, 1);
+#pragma unroll
+        for (int kt = 0; kt < NT; ++kt) {
+            if (kt + 1 < NT) wait_vmcnt_le<4>(); else wait_vmcnt_le<0>();
+            raw_barrier();
+            const char* b = sLand + (kt & 1) * 16384;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int row = 64 * wave + 32 * j + l31;
+                    a[j][2 * kt + ks] = *reinterpret_cast<const half8_t*>(b + row * 64 + (((2 * ks + lhi) ^ ((row >> 2) & 3)) << 4));
+                }
+            raw_barrier();      // (waits lgkmcnt(0)): every wave has its fragments before the buffer is refilled
+            if (kt + 2 < NT) issue_a(kt + 2, kt & 1);
+        }
+    }
+    if (!GEGLU && p.R) issue_r(c_begin * G4_BN, lane);
+    wait_vmcnt_le<0>();
+    raw_barrier();              // W chunks 0 / 1, bias group 0 and the first residual rows are in LDS for every wave
+
+    // ---- sweep over the output columns ------------------------------------------------------------------------------
+    // Per chunk: compute(c) from ring slot c&1 -> [own W(c+1), R(c) landed: vmcnt] -> ONE barrier (slot c&1 is free, every
+    // wave's part of W(c+1) is visible) -> issue W(c+2) into the freed slot -> wave-private epilogue(c).  W is requested two
+    // chunks ahead of its use and BEFORE the stores of the chunk in between, so no wait ever has a store in front of it.
+    const float inv_alpha = 1.0f / p.alpha;
+    const int wfrag_off = l31 * 128;            // + ((slot ^ ((l31 >> 1) & 7)) << 4) per slice
+    const int wsw = (l31 >> 1) & 7;
+    bool stored_prev = false;                   // did the previous chunk end with its four stores? (GEGLU: every 2nd)
+#ifndef MC_EMU
+    // PROFILING ONLY (dbg & 16): s_memtime stamps of the first 32 chunks, [workgroup][wave][chunk][6], through p.ws
+    unsigned long long* stamps = (p.dbg & 16) && p.ws ? reinterpret_cast<unsigned long long*>(p.ws) + ((size_t)pid * 4 + wave) * 32 * 6 : nullptr;
+#define G4_STAMP(k) if (stamps && ci < 32 && lane == 0) stamps[ci * 6 + (k)] = __builtin_readcyclecounter()
+#else
+#define G4_STAMP(k)
+#endif
+#pragma unroll 1
+    for (int ci = 0; ci < nchunks; ++ci) {
+        const int c = c_begin + ci;
+        G4_STAMP(0);
+        f32x16 acc[2];
+        if (p.bias) {   // accumulators start as the bias: acc[r] belongs to column 8*(r>>2) + 4*lhi + (r&3)
+            const float* bt = reinterpret_cast<const float*>(sBias + ((ci >> 3) & 1) * 1024) + (ci & 7) * G4_BN + 4 * lhi;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                f32x4 bq = *reinterpret_cast<const f32x4*>(bt + 8 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[0][4 * q + e] = acc[1][4 * q + e] = bq[e] * inv_alpha;   // out = alpha * acc
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = acc[1][r] = 0.f;
+        }
+        const char* bW = sW + (ci & 1) * L::wchunk + wfrag_off;
+        half8_t wf[3];
+        wf[0] = *reinterpret_cast<const half8_t*>(bW + (((0 + lhi) ^ wsw) << 4));
+        wf[1] = *reinterpret_cast<const half8_t*>(bW + (((2 + lhi) ^ wsw) << 4));
+        if (!(p.dbg & 2))
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            // fragment of slice s+2 requested before the MFMAs of slice s: three register sets, two reads in flight, so
+            // the ds_read latency (~100+ cycles) runs under four MFMAs; the fences keep hipcc from sinking the read
+            // back to its use (it otherwise folds the ring into one register set with lgkmcnt(0) per slice)
+            if (s + 2 < KS)
+                wf[(s + 2) % 3] = *reinterpret_cast<const half8_t*>(bW + ((s + 2) >> 2) * 4096 +
+                                                                   (((2 * ((s + 2) & 3) + lhi) ^ wsw) << 4));
+#ifndef MC_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            acc[0] = mfma32(wf[s % 3], a[0][s], acc[0]);
+            acc[1] = mfma32(wf[s % 3], a[1][s], acc[1]);
+#ifndef MC_EMU
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+        G4_STAMP(1);
+        if (ci > 0) {   // everything this wave issued before the previous chunk's stores (if it had any) has landed
+            if (stored_prev) wait_vmcnt_le<4>(); else wait_vmcnt_le<0>();
+        }
+        G4_STAMP(2);
+        raw_barrier();
+        G4_STAMP(3);
+        if (ci + 2 < nchunks && !(p.dbg & 8)) issue_w(c + 2, ci & 1);
+        if (wave == 0 && p.bias && (ci & 7) == 0 && 8 * ((ci >> 3) + 1) < nchunks) issue_bias((ci >> 3) + 1);
+
+        // ---- wave-private epilogue -----------------------------------------------------------------------------------
+        if (p.dbg & 4) { stored_prev = false; continue; }
+        // lane-derived addresses of the epilogue are re-derived here every chunk: hoisted out of the loop they would sit in
+        // (or spill from) VGPRs that the resident A fragments need
+        const int ln = opaque(lane);
+        const int e31 = ln & 31, ehi = ln >> 5;
+        constexpr int GRP = GEGLU ? 4 : 2;                 // chunks per 128-byte store group
+        const int gi = ci % GRP;                           // position of this chunk inside its group (c_begin is a multiple of GRP)
+        const bool flush = gi == GRP - 1 || ci + 1 == nchunks;
+        if (GEGLU) {
+            // W rows interleaved (h_j, gate_j): acc[4q+0], acc[4q+2] are h, acc[4q+1], acc[4q+3] their gates; the chunk
+            // yields 16 output columns = staging slots 2*gi, 2*gi + 1
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half2_t h;
+                    h[0] = to_half(acc[j][4 * q + 0] * gelu_f(acc[j][4 * q + 1]));
+                    h[1] = to_half(acc[j][4 * q + 2] * gelu_f(acc[j][4 * q + 3]));
+                    const int col = 16 * gi + 4 * q + 2 * ehi;     // column inside the group, 2 halfs
+                    *reinterpret_cast<half2_t*>(sStg + g4_stg_off(32 * j + e31, col >> 3) + (col & 7) * 2) = h;
+                }
+        } else {
+            const bool scale = p.alpha != 1.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    half4_t h;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) h[e] = to_half(scale ? acc[j][4 * q + e] * p.alpha : acc[j][4 * q + e]);
+                    char* dst = sStg + g4_stg_off(32 * j + e31, 4 * gi + q) + ehi * 8;
+                    if (p.R) {   // the reference adds the residual to the layer's fp16 output in fp16 (attention.py:285-296)
+                        const half4_t r = *reinterpret_cast<const half4_t*>(dst);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) h[e] = (half_t)((float)h[e] + (float)r[e]);
+                    }
+                    *reinterpret_cast<half4_t*>(dst) = h;
+                }
+        }
+        stored_prev = flush;
+        if (!flush) continue;
+        wave_lds_sync();
+        // read-back + store in two halves of 32 rows (16 VGPRs of data in flight, the kernel sits at the 256-register
+        // limit); the next group's residual rows are requested between them, once the whole image has been read.
+        // Vector-memory order of a flushing chunk: [W(c+2) x5][bias][stores x4][R x8][stores x4] -> the next chunk's
+        // `vmcnt <= 4` retires everything but the last four stores.
+        const int grp = c / GRP;                           // absolute store-group index
+        const int npieces = (gi + 1) * (8 / GRP);          // 16-byte pieces of the row that hold data (8 for a full group)
+        half8_t o[4];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                o[it] = *reinterpret_cast<const half8_t*>(sStg + g4_stg_off(32 * hh + 8 * it + (ln >> 3), ln & 7));
+            wave_lds_sync();
+            if (hh == 1) {   // the image is in registers: it may take the next group's residual rows
+                G4_STAMP(4);
+                if (!GEGLU && p.R && ci + 1 < nchunks) issue_r((grp + 1) * 64, ln);
+            }
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int m = m0 + 64 * wave + 32 * hh + 8 * it + (ln >> 3);
+                const uint32_t voff = (m < p.M && (ln & 7) < npieces) ? ((uint32_t)m * (uint32_t)p.ldc + (uint32_t)(grp * 64 + (ln & 7) * 8)) * 2u : kOOB;
+                gbuf_st8(bufC, (p.dbg & 1) ? kOOB : voff, o[it]);
+            }
+        }
+        G4_STAMP(5);
+    }
+}
+
+template <int KS, bool GEGLU>
+static int launch4(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t bC, uint32_t bR, uint32_t bB, int nsplit,
+                   hipStream_t stream) {
+    const int tilesM = (p.M + G4_BM - 1) / G4_BM;
+    const int nchunk_all = p.N / G4_BN;
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > nchunk_all) nsplit = nchunk_all;
+    int chunks = (nchunk_all + nsplit - 1) / nsplit;
+    const int grp = GEGLU ? 4 : 2;                // chunks per 128-byte store group: ranges start at a group boundary
+    chunks = (chunks + grp - 1) / grp * grp;
+    nsplit = (nchunk_all + chunks - 1) / chunks;
+    const size_t smem = G4Lds<KS>::total;
+    allow_big_smem(gemm4_kernel<KS, GEGLU>, smem);
+    dim3 grid((unsigned)(((tilesM + 7) / 8) * 8 * nsplit));
+    MC_LAUNCH((gemm4_kernel<KS, GEGLU>), grid, dim3(256), smem, stream, p, bA, bW, bC, bR, bB, tilesM, nsplit, chunks);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// DENSE, single A source, K = 320, N % 32 == 0, one bias row; optional residual, or the fused GEGLU epilogue (W rows
+// interleaved (h_j, gate_j), C gets N/2 columns).  nsplit = workgroups sharing one 256-row block of A (0 = automatic).
+// Returns MC_ERR_UNSUPPORTED for anything else (the caller falls back to the tiled kernels).
+int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream) {
+    if (p.A2 || p.K != 320 || p.N % G4_BN || (p.ws && !(p.dbg & 16)) || p.splits != 1) return MC_ERR_UNSUPPORTED;
+    if (p.epi && (p.R || p.alpha != 1.0f)) return MC_ERR_UNSUPPORTED;
+    if (p.bias && p.rows_per_batch < p.M) return MC_ERR_UNSUPPORTED;
+    if ((p.ldc & 7) || (p.R && (p.ldr & 7)) || (p.lda & 7)) return MC_ERR_UNSUPPORTED;
+    const int ncol = p.epi ? p.N / 2 : p.N;
+    const size_t lim = 0x7FFFFFF0u;
+    const size_t bA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bW = (size_t)p.N * p.K * 2;
+    const size_t bC = ((size_t)(p.M - 1) * p.ldc + ncol) * 2;
+    const size_t bR = p.R ? ((size_t)(p.M - 1) * p.ldr + p.N) * 2 : 0, bB = (size_t)p.N * 4;
+    if (bA > lim || bW > lim || bC > lim || bR > lim) return MC_ERR_UNSUPPORTED;
+    if (nsplit <= 0) {   // two workgroups per CU want >= 512 of them; more splits re-read A from L2, fewer idle CUs
+        const int tilesM = (p.M + G4_BM - 1) / G4_BM;
+        nsplit = 1;
+        while (tilesM * nsplit < 448 && (p.N / G4_BN) / (nsplit * 2) >= 5) nsplit *= 2;
+    }
+    if (p.epi)
+        return launch4<20, true>(p, (uint32_t)bA, (uint32_t)bW, (uint32_t)bC, (uint32_t)bR, (uint32_t)bB, nsplit, stream);
+    return launch4<20, false>(p, (uint32_t)bA, (uint32_t)bW, (uint32_t)bC, (uint32_t)bR, (uint32_t)bB, nsplit, stream);
+}
+
+}  // namespace mc

@@ -1,0 +1,241 @@
+// C entry points of the GEMM / implicit-conv family (include/mc_kernels.h) and the choice of kernel structure:
+//   gemm4.hip  streaming, A-stationary (short-K Linear layers of the 64x64 level, K = 320)
+//   gemm3.hip  256x320 / 128x320 tiles, 8 / 4 waves (everything that still fills the 256 CUs with them), split-K
+//   gemm2.hip  128x128 / 64x64 tiles (small problems of the 16x16 / 8x8 levels)
+// All kernels address their operands through 32-bit buffer descriptors (hardware range check = zero fill for conv
+// padding and tails), so an operand must stay below 2 GiB: larger problems are cut into row ranges here.
+#include "gemm_params.hpp"
+
+namespace mc {
+int gemm2_dispatch(const GemmParams& p, int mode, int small_tile, int deep, size_t rowsA, hipStream_t stream);   // gemm2.hip
+int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStream_t stream);                    // gemm3.hip
+int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream);                                         // gemm4.hip
+}  // namespace mc
+
+using namespace mc;
+
+// PROFILING ONLY (tools/): timing experiments that drop parts of a GEMM kernel (GemmParams::dbg); results are garbage.
+static int g_gemm_debug = 0;
+static float* g_gemm_debug_buf = nullptr;
+extern "C" int mc_gemm_debug(int bits) {
+    g_gemm_debug = bits;
+    return 0;
+}
+extern "C" int mc_gemm_debug_buffer(void* buf) {   // device buffer for in-kernel cycle stamps (bit 16)
+    g_gemm_debug_buf = (float*)buf;
+    return 0;
+}
+
+static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int nsplit, hipStream_t s) {
+    const int M = p.M, N = p.N;
+    const size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (p.Ho * p.Wo)) * p.Hs * p.Ws;
+    if (big_cfg == 10) return mode == DENSE ? gemm4_dispatch(p, nsplit, s) : MC_ERR_UNSUPPORTED;
+    if (!big_cfg && !tile && !deep) {
+        // measured on MI355X (profiles/r02_gemm4_microbench.md): the streaming kernel wins on the K = 320 Linear layers once
+        // the problem has >= 256 row blocks of work; the 256x320 / 128x320 tiles win wherever they still fill the 256 CUs;
+        // smaller problems stay on the 128x128 / 64x64 tiles
+        if (mode == DENSE && p.K == 320 && !p.A2 && (M >= 98304 || (M >= 32768 && N >= 640))) {
+            int rc4 = gemm4_dispatch(p, 0, s);
+            if (rc4 != MC_ERR_UNSUPPORTED) return rc4;
+        }
+        if (N % 320 == 0) {
+            long b1 = (long)((M + 255) / 256) * (N / 320), b4 = (long)((M + 127) / 128) * (N / 320);
+            if (b1 >= 224) big_cfg = 1;
+            else if (b4 >= 192) big_cfg = 4;
+        }
+    }
+    if (big_cfg) {
+        int rc3 = gemm3_dispatch(p, mode, big_cfg, rowsA, s);
+        if (rc3 != MC_ERR_UNSUPPORTED) return rc3;
+    }
+    int small_tile = tile == 64;
+    if (tile == 0) {   // fall to 64x64 tiles when 128x128 would leave most of the 256 CUs idle
+        long big = (long)((M + 127) / 128) * ((N + 127) / 128);
+        small_tile = big < 256;
+    }
+    return gemm2_dispatch(p, mode, small_tile, deep, rowsA, s);
+}
+
+extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
+                           const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
+                           int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
+                           int rows_per_batch, float alpha, int flags, void* stream) {
+    const int tile = flags & 0xFF;        // 0 = auto, 64, 128
+    const int epi = (flags & 0x200) ? 1 : 0;   // fused GEGLU epilogue (weights row-interleaved h/gate)
+    const int deep = (flags & 0x400) ? 1 : 0;  // 3-stage LDS ring of the small-tile kernels
+    const int big_cfg = (flags >> 12) & 0xF;   // 0 = automatic; 1..5 gemm3 geometries; 10 = gemm4
+    const int nsplit = (flags >> 16) & 0xF;    // gemm4: workgroups per 256-row block (0 = automatic)
+    if (M <= 0 || N <= 0 || K <= 0) return MC_ERR_SHAPE;
+    if (flags & 0x100) return MC_ERR_UNSUPPORTED;   // the first-generation kernel is no longer part of the library
+    if (epi && (R || N % 8)) return MC_ERR_UNSUPPORTED;
+    if (K % BK || N % 4 || ldc % 4 || (R && (ldr % 4))) return MC_ERR_SHAPE;
+    if (lda % 8 || (A2 && lda2 % 8)) return MC_ERR_SHAPE;
+    if (mode < 0 || mode > 4) return MC_ERR_UNSUPPORTED;
+    if (mode == DENSE) ctot = K;
+    if (ctot <= 0 || ctot % BK || c1 % BK || c1 > ctot) return MC_ERR_SHAPE;
+    if (c1 < ctot && !A2) return MC_ERR_SHAPE;
+    if (mode != DENSE) {
+        if (K != 9 * ctot || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return MC_ERR_SHAPE;
+        if (M % (Ho * Wo)) return MC_ERR_SHAPE;
+    }
+    if (rows_per_batch <= 0) rows_per_batch = M;
+    GemmParams p;
+    p.A = (const half_t*)A; p.A2 = (const half_t*)A2; p.W = (const half_t*)W;
+    p.C = (half_t*)C; p.R = (const half_t*)R; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
+    p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
+    p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi;
+    static const int dbg_env = getenv("MC_GEMM_DEBUG") ? atoi(getenv("MC_GEMM_DEBUG")) : 0;
+    p.dbg = dbg_env | g_gemm_debug;
+    p.ws = (p.dbg & 16) ? g_gemm_debug_buf : nullptr;
+    p.splits = 1;
+    p.s2_pad = (flags & 0x800) ? 0 : 1;
+    hipStream_t s = (hipStream_t)stream;
+
+    // 2 GiB descriptor limit: cut the problem into row ranges (whole frames for the conv modes).  With a per-batch bias
+    // every range either holds whole batch entries or lies inside one, so its bias rows are a contiguous slice.
+    static const size_t lim_env = getenv("MC_GEMM_OPERAND_LIMIT") ? (size_t)atol(getenv("MC_GEMM_OPERAND_LIMIT")) : 0;   // tests
+    const size_t lim = lim_env ? lim_env : (size_t)0x7FFFFFF0u;
+    const size_t out_cols = epi ? (size_t)N / 2 : (size_t)N;
+    const size_t per_out_row = 2 * (size_t)std::max(std::max(ldc, ldr), (int)out_cols);
+    size_t in_rows_per_unit, out_rows_per_unit, per_in_row = 2 * (size_t)std::max(lda, A2 ? lda2 : 0);
+    if (mode == DENSE) {
+        in_rows_per_unit = out_rows_per_unit = 1;
+    } else {
+        in_rows_per_unit = (size_t)Hs * Ws;
+        out_rows_per_unit = (size_t)Ho * Wo;
+    }
+    const size_t units = (size_t)M / out_rows_per_unit;
+    const size_t bytes_per_unit = std::max(in_rows_per_unit * per_in_row, out_rows_per_unit * per_out_row);
+    size_t units_per_call = units;
+    if (units * bytes_per_unit > lim) {
+        units_per_call = lim / bytes_per_unit;
+        if (units_per_call == 0) return MC_ERR_UNSUPPORTED;
+        if (bias && (size_t)rows_per_batch < (size_t)M) {   // keep every range inside / aligned with the bias batches
+            const size_t upb = (size_t)rows_per_batch / out_rows_per_unit;   // units per batch entry
+            if (upb == 0 || (size_t)rows_per_batch % out_rows_per_unit) return MC_ERR_UNSUPPORTED;
+            if (units_per_call >= upb) units_per_call = units_per_call / upb * upb;
+            else while (upb % units_per_call) --units_per_call;
+        }
+    }
+    for (size_t u0 = 0; u0 < units; u0 += units_per_call) {
+        const size_t nu = std::min(units_per_call, units - u0);
+        GemmParams q = p;
+        const size_t in0 = u0 * in_rows_per_unit, out0 = u0 * out_rows_per_unit;
+        q.M = (int)(nu * out_rows_per_unit);
+        q.A = p.A + in0 * lda;
+        if (A2) q.A2 = p.A2 + in0 * lda2;
+        q.C = p.C + out0 * ldc;
+        if (R) q.R = p.R + out0 * ldr;
+        if (bias && (size_t)rows_per_batch < (size_t)M) {
+            q.bias = bias + (out0 / rows_per_batch) * (size_t)N;
+            q.rows_per_batch = rows_per_batch;
+            if (out0 % rows_per_batch) return MC_ERR_UNSUPPORTED;
+        } else {
+            q.rows_per_batch = q.M;
+        }
+        int rc = gemm_one(q, mode, tile, deep, big_cfg, nsplit, s);
+        if (rc != MC_OK) return rc;
+    }
+    return MC_OK;
+}
+
+// ---- split-K ------------------------------------------------------------------------------------------------------
+namespace mc {
+// out[m][n..n+3] = sum_s ws[s][m][n..] + bias[m / rows_per_batch][n..] + R[m][n..]
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* ws, int splits, half_t* C, int ldc,
+                                                            const half_t* R, int ldr, const float* bias, int M, int N,
+                                                            int rows_per_batch) {
+    const int nv = N / 4;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long)M * nv) return;
+    const int m = (int)(idx / nv), n = (int)(idx - (long)m * nv) * 4;
+    f32x4 v = *reinterpret_cast<const f32x4*>(ws + (size_t)m * N + n);
+    for (int s = 1; s < splits; ++s) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(ws + ((size_t)s * M + m) * N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += x[e];
+    }
+    if (bias) {
+        f32x4 b = *reinterpret_cast<const f32x4*>(bias + (size_t)(m / rows_per_batch) * N + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += b[e];
+    }
+    if (R) {
+        half4_t r = ld4(R + (size_t)m * ldr + n);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r[e];
+    }
+    half4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+    st4(C + (size_t)m * ldc + n, o);
+}
+}  // namespace mc
+
+// How many K ranges mc_gemm_splitk_f16 should be given for this problem: returns 1 (= use mc_gemm_f16) or
+// splits | (geometry << 8), geometry = the gemm3 cfg to pass in flags bits 12-15.  Policy, measured on
+// MI355X: the 8x8 / 16x16-level 3x3 convs (M <= 4096 rows, K = 11520 or 23040) leave 128x320 tiles on a fraction of
+// the CUs or fall to 64x64 tiles at ~300 TFLOP/s; splitting K over up to 8 workgroups per tile fills the chip with
+// the efficient geometry and costs one fp32 round trip of the (small) output (8x8 level: 143 -> 95 us at B = 2,
+// 123 -> 60 us at B = 1; 16x16 level at B = 1: 189 -> 153 us).
+extern "C" int mc_gemm_splitk_plan(int M, int N, int K, int mode) {
+    (void)mode;
+    if (N % 320 || K < 2304 || M <= 0) return 1;
+    const int nk = K / BK;
+    long t1 = (long)((M + 255) / 256) * (N / 320), t4 = (long)((M + 127) / 128) * (N / 320);
+    if (t1 >= 224) return 1;                       // 256x320 tiles already fill the chip
+    int s, cfg;
+    if (t1 >= 64) {                                // 64..223 big tiles: keep the efficient geometry, 2-4 K ranges
+        s = (int)(256 / t1);
+        cfg = 1;
+    } else {                                       // fewer: 128x320 tiles, up to 8 K ranges
+        if (t4 >= 256) return 1;
+        s = (int)(256 / t4);
+        cfg = 4;
+    }
+    if (s > 8) s = 8;
+    while (s > 1 && nk / s < 8) --s;
+    return s < 2 ? 1 : (s | (cfg << 8));
+}
+
+// Same contract as mc_gemm_f16 (no GEGLU epilogue), K split into `splits` ranges.  ws: fp32 workspace of
+// splits * M * N elements.  flags bits 12-15 choose the gemm3 geometry (default 4: 128x320 tiles).
+extern "C" int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
+                                  const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1,
+                                  int ctot, int mode, int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha,
+                                  int flags, float* ws, int splits, void* stream) {
+    int cfg = (flags >> 12) & 0xF;
+    if (!cfg) cfg = 4;
+    if (M <= 0 || N <= 0 || K <= 0 || !ws || splits < 1) return MC_ERR_SHAPE;
+    if (flags & 0x200) return MC_ERR_UNSUPPORTED;
+    if (cfg > 5) return MC_ERR_UNSUPPORTED;
+    if (K % BK || N % 4 || ldc % 4 || (R && (ldr % 4))) return MC_ERR_SHAPE;
+    if (lda % 8 || (A2 && lda2 % 8)) return MC_ERR_SHAPE;
+    if (mode < 0 || mode > 4) return MC_ERR_UNSUPPORTED;
+    if (mode == DENSE) ctot = K;
+    if (ctot <= 0 || ctot % BK || c1 % BK || c1 > ctot) return MC_ERR_SHAPE;
+    if (c1 < ctot && !A2) return MC_ERR_SHAPE;
+    if (mode != DENSE) {
+        if (K != 9 * ctot || Hs <= 0 || Ws <= 0 || Ho <= 0 || Wo <= 0) return MC_ERR_SHAPE;
+        if (M % (Ho * Wo)) return MC_ERR_SHAPE;
+    }
+    if (splits > K / BK) splits = K / BK;
+    if (rows_per_batch <= 0) rows_per_batch = M;
+    GemmParams p;
+    p.A = (const half_t*)A; p.A2 = (const half_t*)A2; p.W = (const half_t*)W;
+    p.C = (half_t*)C; p.R = nullptr; p.bias = nullptr;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
+    p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
+    p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = 0; p.dbg = 0;
+    p.ws = ws; p.splits = splits;
+    p.s2_pad = (flags & 0x800) ? 0 : 1;
+    hipStream_t s = (hipStream_t)stream;
+    size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
+    int rc = gemm3_dispatch(p, mode, cfg, rowsA, s);
+    if (rc != MC_OK) return rc;
+    long nthr = (long)M * (N / 4);
+    MC_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, s, ws, splits, (half_t*)C, ldc,
+              (const half_t*)R, ldr, bias, M, N, rows_per_batch);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}

@@ -141,6 +141,20 @@ __device__ __forceinline__ half8_t gbuf_ld8(GBuf b, uint32_t voff) {
     return __builtin_bit_cast(half8_t, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, 0, 0));
 }
 #endif
+// 16-byte buffer store with the hardware range check (offset at / beyond the buffer's size: nothing is written)
+#ifdef MC_EMU
+__device__ inline void gbuf_st8(GBuf b, uint32_t voff, half8_t v) {
+    if ((uint64_t)voff + 16 <= b.bytes) memcpy(const_cast<char*>(b.base) + voff, &v, 16);
+}
+// make this wave's earlier LDS writes visible to its own later LDS reads (same-wave LDS operations execute in order on the
+// hardware; the simulator runs lanes as fibers, so every lane has to reach this point first)
+__device__ inline void wave_lds_sync() { (void)hipemu::shfl(0, 0); }
+#else
+__device__ __forceinline__ void gbuf_st8(GBuf b, uint32_t voff, half8_t v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, (int)voff, 0, 0);
+}
+__device__ __forceinline__ void wave_lds_sync() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#endif
 // counted wait on this wave's outstanding vector-memory operations, and a bare workgroup barrier (no fence)
 #ifdef MC_EMU
 template <int N>
@@ -155,6 +169,16 @@ __device__ __forceinline__ void raw_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+}
+#endif
+// Identity the optimiser cannot see through: address arithmetic derived from the result is recomputed where it is used
+// instead of being hoisted out of a long loop and kept (or spilled) in VGPRs for its whole duration.
+#ifdef MC_EMU
+__device__ inline int opaque(int x) { return x; }
+#else
+__device__ __forceinline__ int opaque(int x) {
+    asm volatile("" : "+v"(x));
+    return x;
 }
 #endif
 // A voffset beyond every buffer we describe (callers keep buffers <= 2 GiB): forces the zero fill without any

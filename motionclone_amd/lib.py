@@ -26,6 +26,8 @@ SIGNATURES = {
     "mc_workspace_bytes_tattn_loss": [I, I, I],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
     "mc_gemm_splitk_plan": [I, I, I, I],
+    "mc_gemm_debug": [I],
+    "mc_gemm_debug_buffer": [P],
     "mc_softmax_rows_f16": [P, I, I, I, P],
     "mc_video_post_f32": [P, I, P, I, I, I, P],
     "mc_vae_sample_f16": [P, I, P, P, I, I, I, P],

@@ -75,8 +75,8 @@ def workspace(op, like, *dims):
 _SPLIT_PLAN = {}   # (M, N, K, mode) -> mc_gemm_splitk_plan, memoised: one ctypes round trip less per launch
 
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
-         rows_per_batch=0, tile=0, m_out=None, v1=False, geglu=False, deep=False, cfg=0, splits=None,
-         pad_front=True):
+         rows_per_batch=0, tile=0, m_out=None, geglu=False, deep=False, cfg=0, splits=None,
+         pad_front=True, nsplit=0):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
 
     geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
@@ -99,13 +99,13 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
     if out is None:
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
-    flags = tile | (0x100 if v1 else 0) | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
-        | (0 if pad_front else 0x800)
+    flags = tile | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
+        | (0 if pad_front else 0x800) | (nsplit << 16)
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N
     if splits is None:
-        if geglu or tile or v1 or deep or cfg:
+        if geglu or tile or deep or cfg:
             splits = 1
         else:
             key = (M, N, K, mode, lib.is_emulated())

@@ -98,26 +98,44 @@ class MotionCloneSampler:
         return self
 
     def _graphed_step(self, latents, i, text, rep_dev, ctrl):
-        key = (i, tuple(latents.shape), text.data_ptr(), id(rep_dev), id(ctrl))
+        """One hipGraph per (step index, shapes).  Everything that changes between videos - latents, text embeddings, the
+        motion representation, the SparseCtrl condition - enters through static buffers that are refreshed by copies before
+        the replay, so a graph captured on the first video serves every later (prompt, reference-video) pair."""
+        guided = i < self.G
+        rsig = tuple((k, tuple(v[0].shape)) for k, v in rep_dev.items()) if guided else ()
+        csig = None if ctrl is None else (tuple(ctrl["cond"].shape), float(ctrl.get("scale", 1.0)))
+        key = (i, tuple(latents.shape), tuple(text.shape), rsig, csig)
         ent = self._graphs.get(key)
         if ent is None:
-            static_in = latents.clone()
+            s_lat, s_text = latents.clone(), text.clone()
+            s_rep = {k: tuple(t.clone() for t in v) for k, v in rep_dev.items()} if guided else {}
+            s_ctrl = None if ctrl is None else dict(cond=ctrl["cond"].clone(), mask=ctrl["mask"].clone(), scale=ctrl.get("scale", 1.0))
             side = torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):          # eager pass first: lazy one-time work (function attributes, caches)
-                first = self._step_eager(static_in, i, text, rep_dev, None, ctrl)
+                first = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph, pool=self._graph_pool):
-                static_out = self._step_eager(static_in, i, text, rep_dev, None, ctrl)
+                s_out = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
             if self._graph_pool is None:
                 self._graph_pool = graph.pool()
-            self._graphs[key] = (graph, static_in, static_out, (text, rep_dev, ctrl))   # keep the captured operands alive
+            self._graphs[key] = (graph, s_lat, s_text, s_rep, s_ctrl, s_out)
             return first
-        graph, static_in, static_out, _ = ent
-        static_in.copy_(latents)
+        graph, s_lat, s_text, s_rep, s_ctrl, s_out = ent
+        s_lat.copy_(latents)
+        if text.data_ptr() != s_text.data_ptr():
+            s_text.copy_(text)
+        for k, v in s_rep.items():
+            for dst, src in zip(v, rep_dev[k]):
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src)
+        if s_ctrl is not None:
+            for k in ("cond", "mask"):
+                if ctrl[k].data_ptr() != s_ctrl[k].data_ptr():
+                    s_ctrl[k].copy_(ctrl[k])
         graph.replay()
-        return static_out
+        return s_out
 
     def step(self, latents, i, text, rep_dev, aux=None, ctrl=None):
         """single_step_video (motionclone_functions.py:173-257): text = [uncond, cond] embeddings [2, n, dim];

@@ -88,3 +88,38 @@ def test_groupnorm_single_frame_tiny_grid(backend):
     y = ops.gn_apply(x, None, st_, g, b, False, 1, 7)
     ref = Fn.group_norm(x.float().t().reshape(1, 64, 7), 32).reshape(64, 7).t()
     assert (y.float() - ref).abs().max() < 1e-2
+
+
+def test_gemm_row_range_splitting_below_the_descriptor_limit():
+    """operands above the 2 GiB buffer-descriptor limit are cut into row ranges by the C entry point (whole frames for the
+    conv modes, bias batches kept aligned); exercised in a child process with the limit lowered to 40 KiB"""
+    import os
+    import subprocess
+    import sys
+    code = r'''
+import sys, torch
+sys.path.insert(0, %r)
+from motionclone_amd import lib, build, ops
+lib.use_library_for_tests(build.build_emu())
+import torch.nn.functional as Fn
+g = torch.Generator().manual_seed(0)
+M, N, K = 400, 72, 128
+a = (torch.randn(M, K, generator=g) * 0.5).half(); w = (torch.randn(N, K, generator=g) * 0.1).half()
+bias = torch.randn(4, N, generator=g); res = torch.randn(M, N, generator=g).half()
+out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=100)
+ref = a.float() @ w.float().t() + bias.repeat_interleave(100, 0) + res.float()
+assert (out.float() - ref).abs().max() < 3e-2, (out.float() - ref).abs().max()
+NF, C, H, W = 6, 64, 8, 8
+x = (torch.randn(NF, C, H, W, generator=g)).half(); wc = (torch.randn(72, C, 3, 3, generator=g) * 0.05).half()
+xc = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
+tb = torch.randn(2, 72, generator=g)
+wp = ops.pack_conv_k(wc.float().permute(0, 2, 3, 1).reshape(72, 9, C)).half()
+o = ops.gemm(xc, wp, bias=tb, rows_per_batch=3 * H * W, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
+refc = Fn.conv2d(x.float(), wc.float(), padding=1) + tb.repeat_interleave(3, 0)[:, :, None, None]
+got = o.float().reshape(NF, H, W, 72).permute(0, 3, 1, 2)
+assert (got - refc).abs().max() < 3e-2, (got - refc).abs().max()
+print("split ok")
+''' % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MC_GEMM_OPERAND_LIMIT="40960")
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env)
+    assert r.returncode == 0 and "split ok" in r.stdout, r.stdout[-3000:]

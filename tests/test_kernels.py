@@ -33,12 +33,36 @@ def close(a, b, atol, rtol, what=""):
 
 
 # ---------------------------------------------------------------------------------------------------
-@pytest.fixture(params=[False, True], ids=["v2", "v1"])
-def v1(request):
-    return request.param
 
 
-@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("M,N,nsplit,res,alpha", [(256, 320, 0, True, 1.0), (300, 96, 1, True, 1.0), (515, 640, 2, False, 0.5),
+                                                   (512, 2560, 3, True, 1.0), (100, 64, 1, False, 1.0)])
+def test_gemm4_streaming_short_k(backend, M, N, nsplit, res, alpha):
+    """gemm4.hip (A-stationary streaming kernel of the K = 320 Linear layers): bias as accumulator start, residual added in
+    place in the staging image, 128-byte store groups incl. ragged last group, row tails, column-windowed output, splits"""
+    dev = backend
+    if big(dev):
+        M = M * 37 + 11
+    K = 320
+    a, w = rnd((M, K), dev, 1, 0.5), rnd((N, K), dev, 2, 0.05)
+    bias = torch.randn(1, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    r = rnd((M, N), dev, 4) if res else None
+    wide = torch.zeros((M, N + 32), dtype=torch.float16, device=dev)
+    out = ops.gemm(a, w, bias=bias, residual=r, alpha=alpha, cfg=10, nsplit=nsplit, out=wide[:, 32:])
+    ref = (alpha * (a.float() @ w.float().t()) + bias).half().float()
+    if res:
+        ref = ref + r.float()       # the kernel adds the residual to the rounded fp16 output, as the reference's modules do
+    close(out, ref, 2e-2, 5e-3, "gemm4 dense")
+    assert float(wide[:, :32].abs().max()) == 0.0
+    # fused GEGLU epilogue (row-interleaved weights), 16 output columns per chunk, 4 chunks per store group
+    wg, bg = rnd((2 * N, K), dev, 5, 0.05), torch.randn(2 * N, generator=torch.Generator().manual_seed(6)) * 0.3
+    og = ops.gemm(a, ops.interleave_geglu(wg), bias=ops.interleave_geglu(bg).unsqueeze(0).contiguous().to(dev), geglu=True,
+                  cfg=10, nsplit=nsplit)
+    full = a.float() @ wg.float().t() + bg.to(dev)
+    close(og, full[:, :N] * Fn.gelu(full[:, N:]), 2e-2, 5e-3, "gemm4 geglu")
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
 def test_gemm_large_tile_geometries(backend, cfg):
     """gemm3.hip: every block geometry, dense with bias/residual/tails, conv with concat, fused GEGLU"""
     dev = backend
@@ -60,7 +84,7 @@ def test_gemm_large_tile_geometries(backend, cfg):
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm3 geglu")
 
 
-@pytest.mark.parametrize("splits,cfg", [(2, 0), (3, 4), (5, 1), (4, 6)])
+@pytest.mark.parametrize("splits,cfg", [(2, 0), (3, 4), (5, 1), (4, 5)])
 def test_gemm_split_k(backend, splits, cfg):
     """split-K path: K ranges in separate workgroups -> fp32 partial sums -> reduce kernel with bias / residual"""
     dev = backend
@@ -114,7 +138,7 @@ def test_gemm_geglu_epilogue(backend):
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(200, 72, 128, 64), (300, 136, 192, 128), (77, 64, 64, 0), (1100, 260, 320, 128)])
-def test_gemm_dense(backend, M, N, K, tile, v1):
+def test_gemm_dense(backend, M, N, K, tile):
     dev = backend
     if big(dev):
         M, N, K = M * 8 + 5, N * 4, K * 4
@@ -122,21 +146,21 @@ def test_gemm_dense(backend, M, N, K, tile, v1):
     bias = torch.randn(2, N, generator=torch.Generator().manual_seed(3)).to(dev)
     res = rnd((M, N), dev, 4)
     rpb = (M + 1) // 2
-    out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=rpb, alpha=0.5, tile=tile, v1=v1)
+    out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=rpb, alpha=0.5, tile=tile)
     b_idx = (torch.arange(M, device=dev) // rpb)
     ref = 0.5 * (a.float() @ w.float().t()) + bias[b_idx] + res.float()
     close(out, ref, 2e-2, 5e-3, "gemm")
     # asymmetric operands would expose a transposed C-write; also check no-epilogue path
-    out2 = ops.gemm(a, w, tile=tile, v1=v1)
+    out2 = ops.gemm(a, w, tile=tile)
     close(out2, a.float() @ w.float().t(), 2e-2, 5e-3, "gemm plain")
 
 
-def test_gemm_concat_and_strided_out(backend, v1):
+def test_gemm_concat_and_strided_out(backend):
     dev = backend
     M, C1, C2, N = 130, 64, 128, 96
     a, a2, w = rnd((M, C1), dev, 1), rnd((M, C2), dev, 2), rnd((N, C1 + C2), dev, 3, 0.1)
     wide = torch.zeros((M, 3 * N), dtype=torch.float16, device=dev)
-    ops.gemm(a, w, a2=a2, out=wide[:, N:2 * N], v1=v1)
+    ops.gemm(a, w, a2=a2, out=wide[:, N:2 * N])
     ref = torch.cat([a, a2], 1).float() @ w.float().t()
     close(wide[:, N:2 * N], ref, 2e-2, 5e-3, "gemm concat")
     assert wide[:, :N].abs().max() == 0 and wide[:, 2 * N:].abs().max() == 0
@@ -155,7 +179,7 @@ def _from_cl(x, NF, H, W):
 
 
 @pytest.mark.parametrize("mode", ["s1", "s2", "up", "concat"])
-def test_conv3x3(backend, mode, v1):
+def test_conv3x3(backend, mode):
     dev = backend
     NF, Cin, Cout, H, W = (3, 64, 72, 6, 10) if not big(dev) else (5, 192, 200, 24, 20)
     x = rnd((NF, Cin, H, W), dev, 1)
@@ -164,29 +188,29 @@ def test_conv3x3(backend, mode, v1):
     xc = _to_cl(x)
     wp = _conv_w_pack(w)
     if mode == "s1":
-        out = ops.gemm(xc, wp, bias=bias, v1=v1, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
+        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
         ref = Fn.conv2d(x.float(), w.float(), bias[0], padding=1)
         Ho, Wo = H, W
     elif mode == "s2":
         Ho, Wo = H // 2, W // 2
-        out = ops.gemm(xc, wp, bias=bias, v1=v1, mode=ops.CONV_S2, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
+        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_S2, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
         ref = Fn.conv2d(x.float(), w.float(), bias[0], padding=1, stride=2)
     elif mode == "up":
         Ho, Wo = 2 * H, 2 * W
-        out = ops.gemm(xc, wp, bias=bias, v1=v1, mode=ops.CONV_UP, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
+        out = ops.gemm(xc, wp, bias=bias, mode=ops.CONV_UP, geom=(H, W, Ho, Wo), m_out=NF * Ho * Wo)
         ref = Fn.conv2d(Fn.interpolate(x.float(), scale_factor=2.0, mode="nearest"), w.float(), bias[0], padding=1)
     else:
         x2 = rnd((NF, 128, H, W), dev, 5)
         w = rnd((Cout, Cin + 128, 3, 3), dev, 6, 0.05)
         out = ops.gemm(xc, _conv_w_pack(w), a2=_to_cl(x2), bias=bias, mode=ops.CONV_S1, geom=(H, W, H, W),
-                       m_out=NF * H * W, v1=v1)
+                       m_out=NF * H * W)
         ref = Fn.conv2d(torch.cat([x, x2], 1).float(), w.float(), bias[0], padding=1)
         Ho, Wo = H, W
     close(_from_cl(out, NF, Ho, Wo), ref, 3e-2, 5e-3, "conv " + mode)
 
 
 @pytest.mark.parametrize("stride", [1, 2])
-def test_conv3x3_dgrad(backend, stride, v1):
+def test_conv3x3_dgrad(backend, stride):
     """data-gradient of the 3x3 conv = the same kernel with re-packed weights (autograd is the reference)."""
     dev = backend
     NF, Cin, Cout, H, W = (2, 64, 64, 8, 6) if not big(dev) else (4, 128, 192, 16, 24)
@@ -198,10 +222,10 @@ def test_conv3x3_dgrad(backend, stride, v1):
     Ho, Wo = y.shape[2:]
     if stride == 1:
         wd = ops.pack_conv_k(w.flip(2, 3).permute(1, 2, 3, 0).reshape(Cin, 9, Cout))
-        out = ops.gemm(_to_cl(dy), wd, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, v1=v1)
+        out = ops.gemm(_to_cl(dy), wd, mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W)
     else:
         wd = ops.pack_conv_k(w.permute(1, 2, 3, 0).reshape(Cin, 9, Cout))
-        out = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(Ho, Wo, H, W), m_out=NF * H * W, v1=v1)
+        out = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(Ho, Wo, H, W), m_out=NF * H * W)
     close(_from_cl(out, NF, H, W), ref, 3e-2, 5e-3, "conv dgrad s%d" % stride)
 
 
