@@ -266,7 +266,7 @@ def reference_gpu_baseline(dev, size=512, sched=(30, 18, 0.4)):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2, help="videos timed per GPU")
+    ap.add_argument("--steps", type=int, default=4, help="videos timed per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up videos per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
@@ -277,6 +277,8 @@ def main():
     ap.add_argument("--sparsectrl", action="store_true", help="BASELINE config 4: add the SparseCtrl (i2v_rgb) encoder pass")
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
+    ap.add_argument("--inflight", type=int, default=2, help="independent videos processed concurrently per GPU (own HIP stream, "
+                    "own sampler / graphs each); 1 = strictly one after the other")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -330,18 +332,61 @@ def main():
     probe = GemmProbe()
     probe.install()
     use_graphs = not args.no_graphs
+    # Independent (prompt, reference-video) samples are the unit of parallelism of this workload.  Inside one
+    # GPU `--inflight` of them run concurrently, each on its own HIP stream with its own sampler (and graphs): the launch
+    # sequence of one video leaves CUs idle in kernel tails and in the small 16x16 / 8x8-level kernels, which a second video
+    # fills (measured +7 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).
+    NF = max(1, min(args.inflight, args.steps))
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
+    smps = [smp] + [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
+                                       num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE,
+                                       controlnet=ceng) for _ in range(NF - 1)]
     if use_graphs:
-        smp.enable_graphs()
-    for _ in range(max(1, args.warmup) if use_graphs else args.warmup):   # the first graph pass captures: never timed
-        out = one_video(smp, lat, text, vid, noise, ctrl=ctrl)
+        for sm in smps:
+            sm.enable_graphs()
+    # every lane of the in-flight set works on its own example (different seeds = different latents / noise)
+    lane_inputs = [(lat, text, vid, noise)] + [synth_inputs(dev, args.frames, args.size, args.size, seeds[(rank + 1 + k) % len(seeds)] + 7 * (k + 1))
+                                                for k in range(NF - 1)]
+
+    def run_videos(nvideos, step_events=None):
+        """nvideos videos, NF at a time: step i of every in-flight video is issued before step i + 1 of any"""
+        last = None
+        done = 0
+        cur = torch.cuda.current_stream(dev)
+        while done < nvideos:
+            k_act = min(NF, nvideos - done)
+            for st in streams[:k_act]:
+                st.wait_stream(cur)
+            xs, reps = [None] * k_act, [None] * k_act
+            for k in range(k_act):
+                la, tx, vd, nz = lane_inputs[k]
+                with torch.cuda.stream(streams[k]):
+                    reps[k] = smps[k].engine.prepare_representation(smps[k].extract(vd, nz, tx[0:1], add_noise_step=400, ctrl=ctrl))
+                    xs[k] = la
+            for i in range(N_STEPS):
+                for k in range(k_act):
+                    with torch.cuda.stream(streams[k]):
+                        if step_events is not None:
+                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                            e0.record()
+                        xs[k] = smps[k].step(xs[k], i, lane_inputs[k][1], reps[k], ctrl=ctrl)
+                        if step_events is not None:
+                            e1.record()
+                            step_events.append((i < G_STEPS, e0, e1))
+            for st in streams[:k_act]:
+                cur.wait_stream(st)
+            last = xs[0]
+            done += k_act
+        return last
+
+    run_videos(max(NF, args.warmup) if use_graphs else args.warmup * 1)   # every lane's first pass captures: never timed
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     step_events = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = one_video(smp, lat, text, vid, noise, step_events, ctrl=ctrl)
+    out = run_videos(args.steps, step_events)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -376,7 +421,7 @@ def main():
         eager_info = dict(videos_per_min=60.0 / te, sec_per_video=te, identical_to_graph_path=bool(torch.equal(out_e, out)),
                           note="same launch sequence without hipGraphs, one video; not part of `value`")
         del sme
-    graph_info = dict(enabled=use_graphs, graphs=len(smp._graphs) if use_graphs else 0,
+    graph_info = dict(enabled=use_graphs, graphs=sum(len(sm._graphs) for sm in smps) if use_graphs else 0,
                       note="one graph per DDIM step, captured during warm-up; latents / text / representation refreshed by "
                            "device copies into static buffers before each replay; extraction eager")
     vae_info = None
@@ -418,9 +463,12 @@ def main():
                                        (16, 256): "1 shape"}.get((args.frames, args.size), "custom"),
                                       args.frames, args.size, args.size, " + SparseCtrl" if args.sparsectrl else "",
                                       G_STEPS, N_STEPS - G_STEPS, N_STEPS, G_STEPS, G_SCALE),
-                       "videos_per_gpu": args.steps, "parallelism": "replicas x%d" % world},
+                       "videos_per_gpu": args.steps, "videos_in_flight_per_gpu": NF, "parallelism": "replicas x%d" % world},
+            # latency of one step of one video while `videos_in_flight_per_gpu` videos share the GPU, and the throughput view
+            # (wall time per step per video = what the videos/min figure is made of)
             "sec_per_guided_step": sum(gsec) / max(1, len(gsec)), "sec_per_plain_step": sum(psec) / max(1, len(psec)),
             "sec_per_denoise_step": (sum(gsec) + sum(psec)) / max(1, len(gsec) + len(psec)),
+            "sec_per_denoise_step_throughput": elapsed / (args.steps * N_STEPS),
             "e2e_tflops_per_gpu": tflop_video * args.steps / elapsed,
             "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
             "roofline": roof,
@@ -435,7 +483,7 @@ def main():
             "eager": eager_info,
         }
         if world == 1 and not args.no_cpu_baseline:
-            del eng, smp
+            del eng, smp, smps
             torch.cuda.empty_cache()
             res["reference_gpu_baseline"] = reference_gpu_baseline(dev) if (args.frames, args.size) == (16, 512) else None
             res["cpu_baseline"] = cpu_baseline()

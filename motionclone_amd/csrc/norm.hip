@@ -24,6 +24,34 @@ __device__ __forceinline__ half8_t gn_load(const GnSrc& s, size_t tok, int c) {
     return c < s.c1 ? ld8(s.a + tok * s.lda + c) : ld8(s.b + tok * s.ldb + (c - s.c1));
 }
 
+// Group totals of two [R][ctot] per-channel partial arrays in LDS -> out[g] = (sum, sum) for the 32 groups.  SUB adjacent
+// lanes share a group (32 * SUB <= blockDim.x, SUB a power of two), each sums every SUB-th of the R * cpg partials, then a
+// log2(SUB)-step butterfly; fixed summation order (deterministic).  Replaces a 32-thread serial walk that was the tail of
+// every block (R * cpg * 2 dependent LDS reads).
+__device__ __forceinline__ void gn_group_totals(const float* p1, const float* p2, int R, int ctot, int cpg, float* out) {
+    const int t = threadIdx.x;
+    int SUB = 1;
+    while (64 * SUB <= (int)blockDim.x && SUB < 8) SUB *= 2;
+    const int gsel = t / SUB, sub = t % SUB;
+    float a = 0.f, b = 0.f;
+    if (gsel < 32) {
+        const int items = R * cpg;
+        for (int it = sub; it < items; it += SUB) {
+            const int rr = it / cpg, c = gsel * cpg + it % cpg;
+            a += p1[rr * ctot + c];
+            b += p2[rr * ctot + c];
+        }
+    }
+    for (int mk = 1; mk < SUB; mk <<= 1) {   // every lane of the wave takes part (lanes with gsel >= 32 carry zeros)
+        a += shfl_xor(a, mk);
+        b += shfl_xor(b, mk);
+    }
+    if (gsel < 32 && sub == 0) {
+        out[gsel * 2] = a;
+        out[gsel * 2 + 1] = b;
+    }
+}
+
 // ---- pass 1 of forward stats: per (frame, chunk, group) sum / sum of squares -------------
 // grid (nchunk, frames), block = VC * R threads (VC = ctot/8 vector columns)
 __global__ void gn_partial_kernel(GnSrc s, int R, int nchunk, float* partial) {
@@ -41,7 +69,22 @@ __global__ void gn_partial_kernel(GnSrc s, int R, int nchunk, float* partial) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) sum[e] = sq[e] = 0.f;
     if (r < R) {
-        for (int tk = t0 + r; tk < t1; tk += R) {
+        // four independent 16-byte loads in flight per thread (the loop is a pure HBM stream)
+        int tk = t0 + r;
+        for (; tk + 3 * R < t1; tk += 4 * R) {
+            half8_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) v[u] = gn_load(s, (size_t)frame * s.hw + tk + u * R, col * 8);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    float f = (float)v[u][e];
+                    sum[e] += f;
+                    sq[e] += f * f;
+                }
+        }
+        for (; tk < t1; tk += R) {
             half8_t v = gn_load(s, (size_t)frame * s.hw + tk, col * 8);
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -57,17 +100,7 @@ __global__ void gn_partial_kernel(GnSrc s, int R, int nchunk, float* partial) {
         }
     }
     __syncthreads();
-    if (t < 32) {
-        float a = 0.f, b = 0.f;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) {
-                a += ssum[rr * s.ctot + c];
-                b += ssq[rr * s.ctot + c];
-            }
-        float* o = partial + ((size_t)(frame * nchunk + chunk) * 32 + t) * 2;
-        o[0] = a;
-        o[1] = b;
-    }
+    gn_group_totals(ssum, ssq, R, s.ctot, s.cpg, partial + (size_t)(frame * nchunk + chunk) * 64);
 }
 
 // mode 0: (sum, sumsq) -> (mean, rstd);  mode 1: (s1, s2) -> (s1/n, s2/n)
@@ -177,17 +210,7 @@ __global__ void gn_bwd_partial_kernel(GnSrc s, const half_t* dz, int lddz, const
         }
     }
     __syncthreads();
-    if (t < 32) {
-        float x = 0.f, y = 0.f;
-        for (int rr = 0; rr < R; ++rr)
-            for (int c = t * s.cpg; c < (t + 1) * s.cpg; ++c) {
-                x += s1[rr * s.ctot + c];
-                y += s2[rr * s.ctot + c];
-            }
-        float* o = partial + ((size_t)(frame * nchunk + chunk) * 32 + t) * 2;
-        o[0] = x;
-        o[1] = y;
-    }
+    gn_group_totals(s1, s2, R, s.ctot, s.cpg, partial + (size_t)(frame * nchunk + chunk) * 64);
 }
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); optional accumulate into dx.  Same thread layout
@@ -333,6 +356,66 @@ __global__ __launch_bounds__(256) void ln_fwd_kernel(const half_t* x, int ldx, h
                 st8(y + (size_t)row * ldy + vi * 8, o);
             }
         }
+    }
+}
+
+// LayerNorm forward for the widths of the UNet (C = 320 / 640 / 1280 = 40 vectors x LPR lanes): a row is owned by LPR
+// adjacent lanes (8 / 16 / 32), five 16-byte vectors each, so all 64 lanes of a wave carry data (the one-row-per-wave
+// kernel above leaves 24 of 64 lanes idle at C = 320) and a wave streams 64 / LPR rows at once; row statistics by an
+// LPR-lane butterfly.  Same arithmetic (two-pass variance), same outputs.
+template <int LPR>
+__global__ __launch_bounds__(256) void ln_fwd5_kernel(const half_t* x, int ldx, half_t* y, int ldy, const float* gamma,
+                                                       const float* beta, const float* pe, int hw, int nframes_pe,
+                                                       float* stats, int M, int C, float eps) {
+    constexpr int RW = 64 / LPR;
+    const int lane = threadIdx.x & 63;
+    const int j = lane % LPR;
+    const int row = (blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6)) * RW + lane / LPR;
+    const bool live = row < M;
+    half8_t v[5];
+#pragma unroll
+    for (int i = 0; i < 5; ++i) v[i] = live ? ld8(x + (size_t)row * ldx + (j + LPR * i) * 8) : zero8();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += (float)v[i][e];
+#pragma unroll
+    for (int mk = 1; mk < LPR; mk <<= 1) sum += shfl_xor(sum, mk);
+    const float mean = sum / C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 5; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float d = (float)v[i][e] - mean;
+            sq += d * d;
+        }
+#pragma unroll
+    for (int mk = 1; mk < LPR; mk <<= 1) sq += shfl_xor(sq, mk);
+    const float rstd = 1.0f / sqrtf(sq / C + eps);
+    if (!live) return;
+    if (j == 0 && stats) {
+        stats[(size_t)row * 2] = mean;
+        stats[(size_t)row * 2 + 1] = rstd;
+    }
+    const float* perow = pe ? pe + (size_t)((row / hw) % nframes_pe) * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < 5; ++i) {
+        const int c0 = (j + LPR * i) * 8;
+        float gm[8], bt[8], pv[8];
+        ld8f(gamma + c0, gm);
+        ld8f(beta + c0, bt);
+        if (perow) {
+            ld8f(perow + c0, pv);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pv[e] = 0.f;
+        }
+        half8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = to_half(((float)v[i][e] - mean) * rstd * gm[e] + bt[e] + pv[e]);
+        st8(y + (size_t)row * ldy + c0, o);
     }
 }
 
@@ -504,8 +587,19 @@ extern "C" int mc_layernorm_fwd_f16(const void* x, int ldx, void* y, int ldy, co
                                     float* stats, int M, int C, float eps, void* stream) {
     if (M <= 0 || C <= 0 || C % 8 || ldx % 8 || ldy % 8 || C > 1536) return MC_ERR_SHAPE;
     if (pe && (hw <= 0 || nframes_pe <= 0)) return MC_ERR_SHAPE;
-    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
     hipStream_t s = (hipStream_t)stream;
+    if (C % 40 == 0 && (C / 40 == 8 || C / 40 == 16 || C / 40 == 32)) {
+        const int lpr = C / 40, rows_per_block = 4 * (64 / lpr);
+        dim3 g5((M + rows_per_block - 1) / rows_per_block);
+#define LN5(L) MC_LAUNCH(ln_fwd5_kernel<L>, g5, dim3(256), 0, s, (const half_t*)x, ldx, (half_t*)y, ldy, gamma, beta, pe, hw, \
+                         nframes_pe, stats, M, C, eps)
+        if (lpr == 8) LN5(8);
+        else if (lpr == 16) LN5(16);
+        else LN5(32);
+#undef LN5
+        return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+    }
+    dim3 grid((M + 4 * LN_RPW - 1) / (4 * LN_RPW)), block(256);
     int nv = (C / 8 + 63) / 64;
     if (nv == 1)
         MC_LAUNCH(ln_fwd_kernel<1>, grid, block, 0, s, (const half_t*)x, ldx, (half_t*)y, ldy, gamma, beta, pe,
