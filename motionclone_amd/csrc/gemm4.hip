@@ -16,9 +16,9 @@
 //     16 rows x 64 B per instruction (+ the residual, which arrives through LDS-DMA as well) -> buffer stores.  No
 //     barrier, no fp32 staging; the other workgroup on the CU computes meanwhile.
 //   * bias: the accumulators START as the bias (a 1 KiB LDS-DMA per 8 chunks, ds_read_b128 broadcast), no epilogue add.
-// Vector-memory counter discipline: per chunk a wave issues [W(c+2) x5][bias][R(c+1) x4][stores(c) x4] in that order, and
-// waits with `vmcnt <= 4` after the next chunk's MFMAs: everything but those four stores has retired (CDNA4 counts stores
-// in vmcnt and retires in order), so no wait ever has a store of the chunk in flight in front of it.
+// Vector-memory counter discipline: vmcnt counts loads and stores, which retire out of order with respect to each other, so
+// the per-chunk wait is vmcnt(0), placed after the chunk's MFMAs; the loads for later chunks (W two chunks ahead, residual
+// rows, bias) are issued after the chunk's stores, which therefore had a whole chunk of MFMAs to drain when waited for.
 #include "gemm_params.hpp"
 
 namespace mc {
@@ -148,7 +148,6 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
     const float inv_alpha = 1.0f / p.alpha;
     const int wfrag_off = l31 * 128;            // + ((slot ^ ((l31 >> 1) & 7)) << 4) per slice
     const int wsw = (l31 >> 1) & 7;
-    bool stored_prev = false;                   // did the previous chunk end with its four stores? (GEGLU: every 2nd)
 #ifndef MC_EMU
     // PROFILING ONLY (dbg & 16): s_memtime stamps of the first 32 chunks, [workgroup][wave][chunk][6], through p.ws
     unsigned long long* stamps = (p.dbg & 16) && p.ws ? reinterpret_cast<unsigned long long*>(p.ws) + ((size_t)pid * 4 + wave) * 32 * 6 : nullptr;
@@ -196,17 +195,25 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
 #endif
         }
         G4_STAMP(1);
-        if (ci > 0) {   // everything this wave issued before the previous chunk's stores (if it had any) has landed
-            if (stored_prev) wait_vmcnt_le<4>(); else wait_vmcnt_le<0>();
-        }
+        // Everything this wave has in flight must be down before the barrier: W(c+1), the residual rows, the bias - and the
+        // previous chunk's stores.  vmcnt counts loads AND stores, and the two kinds retire out of order with respect to
+        // each other, so a counted wait that leaves "the last n stores" pending can be satisfied while an older LDS-DMA is
+        // still in flight (seen as rare wrong tiles once a second stream competed for the memory pipeline).  Hence
+        // vmcnt(0), and the loads for later chunks are issued AFTER this chunk's stores: the wait then covers stores that
+        // have had a whole chunk of MFMAs to drain.
+        wait_vmcnt_le<0>();
         G4_STAMP(2);
         raw_barrier();
         G4_STAMP(3);
-        if (ci + 2 < nchunks && !(p.dbg & 8)) issue_w(c + 2, ci & 1);
-        if (wave == 0 && p.bias && (ci & 7) == 0 && 8 * ((ci >> 3) + 1) < nchunks) issue_bias((ci >> 3) + 1);
+        const bool more_w = ci + 2 < nchunks && !(p.dbg & 8);
+        const bool more_bias = wave == 0 && p.bias && (ci & 7) == 0 && 8 * ((ci >> 3) + 1) < nchunks;
 
         // ---- wave-private epilogue -----------------------------------------------------------------------------------
-        if (p.dbg & 4) { stored_prev = false; continue; }
+        if (p.dbg & 4) {
+            if (more_w) issue_w(c + 2, ci & 1);
+            if (more_bias) issue_bias((ci >> 3) + 1);
+            continue;
+        }
         // lane-derived addresses of the epilogue are re-derived here every chunk: hoisted out of the loop they would sit in
         // (or spill from) VGPRs that the resident A fragments need
         const int ln = opaque(lane);
@@ -245,13 +252,15 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
                     *reinterpret_cast<half4_t*>(dst) = h;
                 }
         }
-        stored_prev = flush;
-        if (!flush) continue;
+        if (!flush) {
+            if (more_w) issue_w(c + 2, ci & 1);
+            if (more_bias) issue_bias((ci >> 3) + 1);
+            continue;
+        }
         wave_lds_sync();
         // read-back + store in two halves of 32 rows (16 VGPRs of data in flight, the kernel sits at the 256-register
-        // limit); the next group's residual rows are requested between them, once the whole image has been read.
-        // Vector-memory order of a flushing chunk: [W(c+2) x5][bias][stores x4][R x8][stores x4] -> the next chunk's
-        // `vmcnt <= 4` retires everything but the last four stores.
+        // limit).  Vector-memory order of a flushing chunk: [stores x8][W(c+2) x5][bias][R x8]: every load the next
+        // wait needs is YOUNGER than the stores, see above.
         const int grp = c / GRP;                           // absolute store-group index
         const int npieces = (gi + 1) * (8 / GRP);          // 16-byte pieces of the row that hold data (8 for a full group)
         half8_t o[4];
@@ -261,10 +270,7 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
             for (int it = 0; it < 4; ++it)
                 o[it] = *reinterpret_cast<const half8_t*>(sStg + g4_stg_off(32 * hh + 8 * it + (ln >> 3), ln & 7));
             wave_lds_sync();
-            if (hh == 1) {   // the image is in registers: it may take the next group's residual rows
-                G4_STAMP(4);
-                if (!GEGLU && p.R && ci + 1 < nchunks) issue_r((grp + 1) * 64, ln);
-            }
+            if (hh == 1) G4_STAMP(4);
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
                 const int m = m0 + 64 * wave + 32 * hh + 8 * it + (ln >> 3);
@@ -272,6 +278,10 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
                 gbuf_st8(bufC, (p.dbg & 1) ? kOOB : voff, o[it]);
             }
         }
+        if (more_w) issue_w(c + 2, ci & 1);
+        if (more_bias) issue_bias((ci >> 3) + 1);
+        // the staging image is in registers / on its way out: it may take the next group's residual rows
+        if (!GEGLU && p.R && ci + 1 < nchunks) issue_r((grp + 1) * 64, ln);
         G4_STAMP(5);
     }
 }

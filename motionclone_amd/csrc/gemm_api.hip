@@ -34,7 +34,8 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         // measured on MI355X (profiles/r02_gemm4_microbench.md): the streaming kernel wins on the K = 320 Linear layers once
         // the problem has >= 256 row blocks of work; the 256x320 / 128x320 tiles win wherever they still fill the 256 CUs;
         // smaller problems stay on the 128x128 / 64x64 tiles
-        if (mode == DENSE && p.K == 320 && !p.A2 && (M >= 98304 || (M >= 32768 && N >= 640))) {
+        static const int no_g4 = getenv("MC_NO_GEMM4") ? atoi(getenv("MC_NO_GEMM4")) : 0;   // diagnosis only
+        if (!no_g4 && mode == DENSE && p.K == 320 && !p.A2 && (M >= 98304 || (M >= 32768 && N >= 640))) {
             int rc4 = gemm4_dispatch(p, 0, s);
             if (rc4 != MC_ERR_UNSUPPORTED) return rc4;
         }

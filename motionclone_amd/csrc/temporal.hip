@@ -20,6 +20,15 @@
 
 namespace mc {
 
+// K = 16 step as the K = 32 instruction with the upper k-slots zero (the legacy v_mfma_f32_16x16x16_f16 returned wrong sums
+// behind K = 32 steps on one accumulator in attention.hip; it is not used in this library).
+// OPEN ISSUE (round 2, tools/race_hunt*.py): tattn_bwd_kernel is bit-reproducible on its own and under concurrent GEMM /
+// LayerNorm / copy kernels, but whole (pixel, head) units of dq / dk change by ~1 % when spatial-attention (or 128x128 GEMM)
+// workgroups of ANOTHER STREAM share its CUs.  Ruled out: legacy MFMA shape, interleaved accumulator chains, AGPR
+// accumulators, missing MFMA wait states, the ds_bpermute shuffles, out-of-bounds writes of the co-resident kernels.
+// Until it is understood, the sampler runs one video at a time per GPU (bench.py --inflight 1).
+__device__ __forceinline__ f32x4 mfma16z(half4_t a, half4_t b, f32x4 c) { return mfma16k32(cat4(a, zero4()), cat4(b, zero4()), c); }
+
 struct TParams {
     const half_t* q;
     const half_t* k;
@@ -94,7 +103,7 @@ __device__ __forceinline__ void t_scores_T(const TParams& P, const TUnit& u, int
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk) {
             half4_t kf = t_row_frag(P.k, P.ld, P, u, tk, ks, lane);
-            st[tk] = mfma16(kf, qf, st[tk]);
+            st[tk] = mfma16z(kf, qf, st[tk]);
         }
     }
 #pragma unroll
@@ -239,7 +248,7 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
 #pragma unroll
             for (int tk = 0; tk < NT; ++tk) {
                 half4_t vf = t_col_frag(P.v, P.ld, P, u, tk, dt, lane);
-                acc = mfma16(vf, pf[tk], acc);
+                acc = mfma16z(vf, pf[tk], acc);
             }
             int c = 16 * dt + 4 * (lane >> 4);
             if (qf < P.F && c < P.d) {
@@ -253,107 +262,6 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
     if (mode == 2) {
         loss_acc = wave_sum(loss_acc);
         if (lane == 0) unit_loss[unit] = loss_acc;
-    }
-}
-
-// ---- forward, attention output only: one wave per (batch, pixel), all heads ---------------------------------------------
-// The per-(pixel, head) kernel above reads its operands straight into MFMA fragments: 8-byte pieces of 16 different
-// rows per load for q / k and 2-byte gathers for V^T, with rows HW * ld halfs apart - 2.3 TB/s at the 64x64 level.  Here a
-// wave owns one pixel: the q | k | v row segments of a GROUP of heads (SEG = max(80, d) halfs = 160+ contiguous bytes per
-// frame row) go global -> registers -> the wave's LDS tile as full 16-byte vectors, consecutive lanes on consecutive
-// addresses; fragments (incl. the transposed V reads) come from LDS; the group's output tile is assembled in LDS and
-// leaves as the same contiguous row segments.  Same arithmetic as tattn_fwd_kernel mode 0 (bit-identical results).
-template <int NT, int DT>
-__global__ __launch_bounds__(256) void tattn_fwd_px_kernel(TParams P, half_t* o, int ldo, int seg, int wave_lds_halfs) {
-    MC_DYN_SMEM(smem);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const long px = (long)blockIdx.x * (blockDim.x >> 6) + wave;
-    if (px >= (long)P.B * P.HW) return;   // whole wave
-    const int b = (int)(px / P.HW), p = (int)(px % P.HW);
-    const int pitch = seg + 8;                                    // halfs; +16 B: rows start on different banks
-    half_t* X = reinterpret_cast<half_t*>(smem) + (size_t)wave * wave_lds_halfs;   // [3][F][pitch]
-    half_t* O = X + 3 * P.F * pitch;                                               // [F][pitch]
-    const int vps = seg / 8;                                      // 16-byte vectors per row segment
-    const int hg_heads = seg / P.d;
-    const int nvec = 3 * P.F * vps;
-    const int g = lane >> 4, c15 = lane & 15;
-    for (int h0 = 0; h0 < P.heads; h0 += hg_heads) {
-        // ---- stage q | k | v segments of heads [h0, h0 + hg_heads) for the F frames of this pixel -------------------
-        for (int i = lane; i < nvec; i += 64) {
-            const int sidx = i / (P.F * vps), rem = i - sidx * (P.F * vps);
-            const int f = rem / vps, v = rem - f * vps;
-            const half_t* src = sidx == 0 ? P.q : (sidx == 1 ? P.k : P.v);
-            const size_t row = ((size_t)b * P.F + f) * P.HW + p;
-            *reinterpret_cast<half8_t*>(X + (sidx * P.F + f) * pitch + v * 8) = ld8(src + row * P.ld + h0 * P.d + v * 8);
-        }
-        wave_lds_sync();
-        for (int hh = 0; hh < hg_heads; ++hh) {
-            const int hc = hh * P.d;
-#pragma unroll
-            for (int tq = 0; tq < NT; ++tq) {
-                f32x4 st[NT];
-#pragma unroll
-                for (int tk = 0; tk < NT; ++tk) st[tk] = fzero4();
-#pragma unroll
-                for (int ks = 0; ks < DT; ++ks) {
-                    const int c = 16 * ks + 4 * g;
-                    const int fq = 16 * tq + c15;
-                    half4_t qf = (fq < P.F && c < P.d) ? ld4(X + (0 * P.F + fq) * pitch + hc + c) : zero4();
-#pragma unroll
-                    for (int tk = 0; tk < NT; ++tk) {
-                        const int fk = 16 * tk + c15;
-                        half4_t kf = (fk < P.F && c < P.d) ? ld4(X + (1 * P.F + fk) * pitch + hc + c) : zero4();
-                        st[tk] = mfma16(kf, qf, st[tk]);
-                    }
-                }
-#pragma unroll
-                for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        int kv = 16 * tk + 4 * g + i;
-                        st[tk][i] = kv < P.F ? st[tk][i] * P.scale : -INFINITY;
-                    }
-                float m, l;
-                t_softmax_T<NT>(st, m, l);
-                const float inv = 1.0f / l;
-                half4_t pf[NT];
-#pragma unroll
-                for (int tk = 0; tk < NT; ++tk)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) pf[tk][i] = (half_t)(st[tk][i] * inv);
-                const int qf_row = 16 * tq + c15;
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) {
-                    f32x4 acc = fzero4();
-                    const int cch = 16 * dt + c15;              // channel of the V^T row this lane supplies
-#pragma unroll
-                    for (int tk = 0; tk < NT; ++tk) {
-                        half4_t vf;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int f = 16 * tk + 4 * g + j;
-                            vf[j] = (f < P.F && cch < P.d) ? X[(2 * P.F + f) * pitch + hc + cch] : (half_t)0.f;
-                        }
-                        acc = mfma16(vf, pf[tk], acc);
-                    }
-                    const int c = 16 * dt + 4 * g;
-                    if (qf_row < P.F && c < P.d) {
-                        half4_t ov;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) ov[i] = to_half(acc[i]);
-                        st4(O + qf_row * pitch + hc + c, ov);
-                    }
-                }
-            }
-        }
-        wave_lds_sync();
-        // ---- the group's output rows: F x seg halfs, 16-byte vectors, consecutive lanes on consecutive addresses ---------
-        for (int i = lane; i < P.F * vps; i += 64) {
-            const int f = i / vps, v = i - f * vps;
-            const size_t row = ((size_t)b * P.F + f) * P.HW + p;
-            st8(o + row * ldo + h0 * P.d + v * 8, *reinterpret_cast<const half8_t*>(O + f * pitch + v * 8));
-        }
-        wave_lds_sync();   // O / X are reused by the next head group
     }
 }
 
@@ -377,29 +285,40 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
     for (int a = 0; a < NT; ++a)
 #pragma unroll
         for (int b = 0; b < NT; ++b) s[a][b] = sT[a][b] = dp[a][b] = dpT[a][b] = fzero4();
+    // two passes over the head dimension, two accumulator chains each (scores, then dP)
 #pragma unroll
     for (int ks = 0; ks < DT; ++ks) {
-        half4_t qf[NT], kf[NT], vf[NT], of[NT];
+        half4_t qf[NT], kf[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
             qf[t] = t_row_frag(P.q, P.ld, P, u, t, ks, lane);
             kf[t] = t_row_frag(P.k, P.ld, P, u, t, ks, lane);
-            if (dO) {
-                vf[t] = t_row_frag(P.v, P.ld, P, u, t, ks, lane);
-                of[t] = t_row_frag(dO, lddo, P, u, t, ks, lane);
-            }
         }
 #pragma unroll
         for (int tq = 0; tq < NT; ++tq)
 #pragma unroll
             for (int tk = 0; tk < NT; ++tk) {
-                s[tq][tk] = mfma16(qf[tq], kf[tk], s[tq][tk]);    // [q = 4g+i][kv = c15]
-                sT[tq][tk] = mfma16(kf[tk], qf[tq], sT[tq][tk]);  // [kv = 4g+i][q = c15]
-                if (dO) {
-                    dp[tq][tk] = mfma16(of[tq], vf[tk], dp[tq][tk]);
-                    dpT[tq][tk] = mfma16(vf[tk], of[tq], dpT[tq][tk]);
-                }
+                s[tq][tk] = mfma16z(qf[tq], kf[tk], s[tq][tk]);    // [q = 4g+i][kv = c15]
+                sT[tq][tk] = mfma16z(kf[tk], qf[tq], sT[tq][tk]);  // [kv = 4g+i][q = c15]
             }
+    }
+    if (dO) {
+#pragma unroll
+        for (int ks = 0; ks < DT; ++ks) {
+            half4_t vf[NT], of[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                vf[t] = t_row_frag(P.v, P.ld, P, u, t, ks, lane);
+                of[t] = t_row_frag(dO, lddo, P, u, t, ks, lane);
+            }
+#pragma unroll
+            for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk) {
+                    dp[tq][tk] = mfma16z(of[tq], vf[tk], dp[tq][tk]);
+                    dpT[tq][tk] = mfma16z(vf[tk], of[tq], dpT[tq][tk]);
+                }
+        }
     }
 
     // per-query statistics in the transposed orientation (query = 16tq + c15)
@@ -495,9 +414,9 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
             f32x4 aq = fzero4(), ak = fzero4(), av = fzero4();
 #pragma unroll
             for (int t2 = 0; t2 < NT; ++t2) {
-                aq = mfma16(kc[t2], dsT[t][t2], aq);
-                ak = mfma16(qc[t2], ds[t2][t], ak);       // dK^T[d][kv] = sum_q Q^T[d][q] dS[q][kv]
-                if (dO) av = mfma16(oc[t2], pr[t2][t], av);  // dV^T[d][kv] = sum_q dO^T[d][q] P[q][kv]
+                aq = mfma16z(kc[t2], dsT[t][t2], aq);
+                ak = mfma16z(qc[t2], ds[t2][t], ak);       // dK^T[d][kv] = sum_q Q^T[d][q] dS[q][kv]
+                if (dO) av = mfma16z(oc[t2], pr[t2][t], av);  // dV^T[d][kv] = sum_q dO^T[d][q] P[q][kv]
             }
             const int f = 16 * t + c15;
             if (f < P.F && c < P.d) {
@@ -583,25 +502,6 @@ extern "C" int mc_tattn_fwd_f16(const void* q, const void* k, const void* v, int
     if (!t_check(P) || ldo % 4) return MC_ERR_SHAPE;
     int nt = (F + 15) / 16, dt = (d + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
-    // pixel-wave kernel (coalesced row segments through LDS) whenever the vectors are 16-byte aligned and a head group
-    // tiles the heads; otherwise the per-(pixel, head) kernel
-    const int seg = d >= 80 ? d : 80;
-    static const int force_old = getenv("MC_TATTN_OLD") ? atoi(getenv("MC_TATTN_OLD")) : 0;
-    if (!force_old && d % 8 == 0 && ld % 8 == 0 && ldo % 8 == 0 && seg % d == 0 && heads % (seg / d) == 0) {
-        const int wave_halfs = 4 * F * (seg + 8);
-        const int wpb = nt == 1 ? 4 : 2;
-        const size_t smem = (size_t)wpb * wave_halfs * 2;
-        const long npx = (long)B * HW;
-#define CALLPX(NT_, DT_)                                                                                           \
-    do {                                                                                                           \
-        allow_big_smem(tattn_fwd_px_kernel<NT_, DT_>, smem);                                                       \
-        MC_LAUNCH((tattn_fwd_px_kernel<NT_, DT_>), dim3((unsigned)((npx + wpb - 1) / wpb)), dim3(64 * wpb), smem, s, P, \
-                  (half_t*)o, ldo, seg, wave_halfs);                                                               \
-    } while (0)
-        MC_T_DISPATCH(CALLPX)
-#undef CALLPX
-        return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
-    }
 #define CALL(NT_, DT_) t_launch_fwd<NT_, DT_>(P, (half_t*)o, ldo, 0, nullptr, nullptr, nullptr, nullptr, nullptr, s)
     MC_T_DISPATCH(CALL)
 #undef CALL
