@@ -443,6 +443,8 @@ def main():
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")
         if os.path.exists(tfile):
             traffic_tab = json.load(open(tfile))
+        if (args.frames, args.size) != (16, 512):
+            traffic_tab = {}     # the PMC passes were taken at the config-2 shapes only
         roof, roof_all = None, {}
         if groups:
             for name, g in groups.items():
@@ -455,7 +457,8 @@ def main():
             dom = max(groups, key=lambda n: groups[n]["ms"])   # dominant by time inside the timed region
             roof = dict(roof_all[dom], kernel=dom)
         res = {
-            "metric": "videos/min (16f x 512x512 SD1.5+AnimateDiff-v3 arch, 30-step DDIM, 18 guided, MotionClone guidance)",
+            "metric": "videos/min (%df x %dx%d SD1.5+AnimateDiff-v3 arch, %d-step DDIM, %d guided, MotionClone guidance)"
+                      % (args.frames, args.size, args.size, N_STEPS, G_STEPS),
             "value": videos / (elapsed / 60.0), "unit": "videos/min", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
