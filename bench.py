@@ -58,6 +58,7 @@ class GemmProbe:
 
     def __init__(self):
         self.events = []
+        self.shapes = []
         self.enabled = False
         self._orig = ops.gemm
 
@@ -79,8 +80,25 @@ class GemmProbe:
             nbytes = 2.0 * (a.shape[0] * a.shape[1] + (kw["a2"].numel() if kw.get("a2") is not None else 0)
                             + N * K + M * n_out * (2 if kw.get("residual") is not None else 1))
             probe.events.append((gemm_kernel_name(mode, M, N, K), e0, e1, 2.0 * M * N * K, nbytes))
+            probe.shapes.append((mode, M, N, K, bool(kw.get("geglu")), kw.get("residual") is not None))
             return out
         ops.gemm = gemm
+
+    def by_shape(self):
+        """Per (kernel, shape) totals of the probe video: where the GEMM time goes (tools / DESIGN tables)."""
+        rows = {}
+        for (name, e0, e1, fl, nb), sh in zip(self.events, self.shapes):
+            r = rows.setdefault((name,) + sh, dict(launches=0, ms=0.0, flop=0.0, bytes=0.0))
+            r["launches"] += 1
+            r["ms"] += e0.elapsed_time(e1)
+            r["flop"] += fl
+            r["bytes"] += nb
+        out = []
+        for (name, mode, M, N, K, geglu, res), r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
+            out.append(dict(kernel=name, mode=mode, M=M, N=N, K=K, geglu=geglu, residual=res, launches=r["launches"],
+                            ms=r["ms"], avg_us=1e3 * r["ms"] / r["launches"], tflops=r["flop"] / r["ms"] / 1e9,
+                            alg_gbps=r["bytes"] / r["ms"] / 1e6))
+        return out
 
     def summary(self):
         groups = {}
@@ -276,6 +294,7 @@ def main():
     ap.add_argument("--guidance-scale", type=float, default=0.4)
     ap.add_argument("--sparsectrl", action="store_true", help="BASELINE config 4: add the SparseCtrl (i2v_rgb) encoder pass")
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
+    ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     ap.add_argument("--inflight", type=int, default=1, help="independent videos processed concurrently per GPU (own HIP stream, "
                     "own sampler / graphs each).  Default 1: with 2 in flight throughput is +7-9 %% but the temporal-attention "
@@ -439,6 +458,8 @@ def main():
         tg, tp, te = table.get((args.frames, args.size), (float("nan"),) * 3)
         tflop_video = G_STEPS * tg + (N_STEPS - G_STEPS) * tp + te
         groups = probe.summary()
+        if args.shapes_out:
+            json.dump(probe.by_shape(), open(args.shapes_out, "w"), indent=1)
         traffic_tab = {}
         tfile = os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")
         if os.path.exists(tfile):

@@ -64,6 +64,7 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
 /* PROFILING ONLY: timing experiments that drop parts of the GEMM kernels (1 = no global stores, 2 = no MFMA loop,
  * 4 = no epilogue, 8 = no operand staging); outputs are garbage while set.  0 restores normal operation. */
 int mc_gemm_debug(int bits);
+int mc_tattn_debug_buffer(void* device_buffer); /* tools only: intermediates of mc_tattn_bwd_f16 (F <= 16, d = 40), units*64*24 floats */
 int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
 
 /* Split-K variant for small-M / deep-K problems (the 8x8 and 16x16-level 3x3 convs of unet_blocks.py:Downsample3D /

@@ -91,6 +91,42 @@ __device__ __forceinline__ float group_sum(float v) {
     return v + shfl_xor(v, 32);
 }
 
+// Exchange variants for the determinism hunt (tools/race_dump.py): 0 = ds_bpermute (as above), 2 = ds_bpermute with a full
+// lgkmcnt(0) drain behind every exchange, 3 = v_permlane16_swap / v_permlane32_swap (VALU only, no LDS crossbar)
+#ifndef MC_EMU
+__device__ __forceinline__ float xchg16(float v) {   // v[lane ^ 16]
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 16) ? r[0] : r[1]);
+}
+__device__ __forceinline__ float xchg32(float v) {   // v[lane ^ 32]
+    unsigned u = __float_as_uint(v);
+    auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
+}
+#endif
+template <int VAR>
+__device__ __forceinline__ float group_x(float v, int m) {
+#ifndef MC_EMU
+    if constexpr (VAR == 3) return m == 16 ? xchg16(v) : xchg32(v);
+    float r = shfl_xor(v, m);
+    if constexpr (VAR == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
+    return r;
+#else
+    return shfl_xor(v, m);
+#endif
+}
+template <int VAR>
+__device__ __forceinline__ float group_max_v(float v) {
+    v = fmaxf(v, group_x<VAR>(v, 16));
+    return fmaxf(v, group_x<VAR>(v, 32));
+}
+template <int VAR>
+__device__ __forceinline__ float group_sum_v(float v) {
+    v += group_x<VAR>(v, 16);
+    return v + group_x<VAR>(v, 32);
+}
+
 // Scores of query tile tq against all key tiles, transposed orientation:
 // st[tk][i] = scale * S[q = 16tq + (lane&15)][kv = 16tk + 4g + i]; invalid kv -> -inf
 template <int NT, int DT>
@@ -268,16 +304,19 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
 // ---- backward -------------------------------------------------------------------------------
 // inputs: q,k,v (P), dO (may be null), guidance seed (ref_idx/ref_val may be null, coef)
 // outputs: dq, dk, dv with row stride ldg (same token layout)
-template <int NT, int DT>
+template <int NT, int DT, int VAR = 0>
 __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t* dO, int lddo, half_t* dq,
                                                          half_t* dk, half_t* dv, int ldg,
                                                          const uint8_t* ref_idx, const float* ref_val,
-                                                         float seed_coef) {
+                                                         float seed_coef, float* dbg = nullptr) {
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c15 = lane & 15;
     TUnit u = t_unit(P);
     if (!u.live) return;
     const long unit = ((long)u.b * P.HW + u.p) * P.heads + u.h;
+#ifndef MC_EMU
+    if constexpr (VAR == 4) asm volatile("" : "+v"(seed_coef));   // hunt: keep the coefficient out of SGPR operands
+#endif
 
     // S (q rows), S^T (kv rows), dP, dP^T accumulated over the head dimension
     f32x4 s[NT][NT], sT[NT][NT], dp[NT][NT], dpT[NT][NT];  // [tq][tk]
@@ -339,13 +378,13 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
                 sT[tq][tk][i] = kv < P.F ? sT[tq][tk][i] * P.scale : -INFINITY;
                 m = fmaxf(m, sT[tq][tk][i]);
             }
-        m = group_max(m);
+        m = group_max_v<VAR>(m);
         float l = 0.f;
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
             for (int i = 0; i < 4; ++i) l += expf(sT[tq][tk][i] - m);
-        l = group_sum(l);
+        l = group_sum_v<VAR>(l);
         mq[tq] = m;
         lq[tq] = l;
         // P^T, total dP^T (attention path + guidance seed), D = sum_kv P * dP
@@ -362,7 +401,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
                 dpT[tq][tk][i] = d;
                 dsum += pv * d;
             }
-        Dq[tq] = group_sum(dsum);
+        Dq[tq] = group_sum_v<VAR>(dsum);
     }
 
     // dS^T = P^T * (dP^T - D) (fp16 B operands); and the q-row orientation via lane broadcasts
@@ -395,6 +434,19 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
                 ds[tq][tk][i] = (half_t)(pv * (d - D));
             }
         }
+    }
+
+    if constexpr (VAR == 1) {   // tools/race_dump.py: intermediates of tile (0, 0), 24 floats per lane
+        float* o = dbg + ((size_t)unit * 64 + lane) * 24;
+        o[0] = mq[0]; o[1] = lq[0]; o[2] = Dq[0]; o[3] = (float)idxq[0]; o[4] = refq[0];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            o[5 + i] = sT[0][0][i];
+            o[9 + i] = dpT[0][0][i];
+            o[13 + i] = (float)dsT[0][0][i];
+            o[17 + i] = (float)ds[0][0][i];
+        }
+        o[21] = (float)pr[0][0][0]; o[22] = s[0][0][0]; o[23] = dp[0][0][0];
     }
 
     // operand gradients, one 16-wide slice of the head dimension at a time
@@ -446,6 +498,8 @@ __global__ void reduce_sum_kernel(const float* in, long n, float scale, float* o
     if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
 }
 
+static float* g_tattn_debug_buf = nullptr;   // mc_tattn_debug_buffer: intermediates of the F <= 16, d = 40 backward (tools only)
+
 template <int NT, int DT>
 static void t_launch_fwd(const TParams& P, half_t* o, int ldo, int mode, half_t* tv, uint8_t* ti,
                          const uint8_t* ri, const float* rv, float* ul, hipStream_t s) {
@@ -457,8 +511,33 @@ template <int NT, int DT>
 static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* dq, half_t* dk, half_t* dv,
                          int ldg, const uint8_t* ri, const float* rv, float coef, hipStream_t s) {
     long units = (long)P.B * P.HW * P.heads;
+    if constexpr (NT == 1 && DT == 3) {
+        if (g_tattn_debug_buf) {
+            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 1>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
+                      dq, dk, dv, ldg, ri, rv, coef, g_tattn_debug_buf);
+            return;
+        }
+#ifndef MC_EMU
+        const char* var = getenv("MC_TATTN_VARIANT");
+        if (var && var[0] == '2') {
+            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
+                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
+            return;
+        }
+        if (var && var[0] == '4') {
+            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 4>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
+                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
+            return;
+        }
+        if (var && var[0] == '3') {
+            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 3>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
+                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
+            return;
+        }
+#endif
+    }
     MC_LAUNCH((tattn_bwd_kernel<NT, DT>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo, dq, dk,
-              dv, ldg, ri, rv, coef);
+              dv, ldg, ri, rv, coef, (float*)nullptr);
 }
 
 #define MC_T_DISPATCH(CALL)                                                     \
@@ -569,6 +648,11 @@ extern "C" int mc_tattn_bwd_f16(const void* q, const void* k, const void* v, int
     MC_T_DISPATCH(CALL)
 #undef CALL
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_tattn_debug_buffer(void* buf) {   // units * 64 * 24 floats, or null to switch the dump off
+    g_tattn_debug_buf = (float*)buf;
+    return 0;
 }
 
 extern "C" int mc_reduce_sum_f32(const float* in, long n, float scale, float* out, void* stream) {

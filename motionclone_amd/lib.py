@@ -11,7 +11,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libmotionclone_hip.so")
+# MC_HIP_LIB: A/B tooling only (a build of the same sources with other compiler flags); the default is the in-tree library
+HIP_LIB_PATH = os.environ.get("MC_HIP_LIB") or os.path.join(_HERE, "csrc", "libmotionclone_hip.so")
 
 c_int, c_long, c_float, c_void_p = ctypes.c_int, ctypes.c_long, ctypes.c_float, ctypes.c_void_p
 P, I, L, F = c_void_p, c_int, c_long, c_float
@@ -28,6 +29,7 @@ SIGNATURES = {
     "mc_gemm_splitk_plan": [I, I, I, I],
     "mc_gemm_debug": [I],
     "mc_gemm_debug_buffer": [P],
+    "mc_tattn_debug_buffer": [P],
     "mc_softmax_rows_f16": [P, I, I, I, P],
     "mc_video_post_f32": [P, I, P, I, I, I, P],
     "mc_vae_sample_f16": [P, I, P, P, I, I, I, P],
