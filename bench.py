@@ -26,7 +26,7 @@ sys.path.insert(0, ROOT)
 
 from motionclone_amd import lib, ops, spec  # noqa: E402
 from motionclone_amd.engine import UNet3DEngine, default_config  # noqa: E402
-from motionclone_amd.sampler import MotionCloneSampler  # noqa: E402
+from motionclone_amd.sampler import MotionCloneSampler, sample_interleaved  # noqa: E402
 
 # algorithmic work of the reference graph, FLOP = 2*MAC (measured on the reference's own code)
 TFLOP_GUIDED, TFLOP_PLAIN, TFLOP_EXTRACT = 45.50, 35.35, 10.06
@@ -296,10 +296,10 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
-    ap.add_argument("--inflight", type=int, default=1, help="independent videos processed concurrently per GPU (own HIP stream, "
-                    "own sampler / graphs each).  Default 1: with 2 in flight throughput is +7-9 %% but the temporal-attention "
-                    "backward kernel is not bit-reproducible next to another stream's attention kernels (open issue, "
-                    "csrc/temporal.hip), so results could differ from the one-at-a-time run")
+    ap.add_argument("--inflight", type=int, default=2, help="independent videos processed concurrently per GPU (own HIP stream, "
+                    "own sampler / graphs each).  2 in flight: +8-10 %% videos/min at config 2 (kernel tails and the small "
+                    "16x16 / 8x8-level kernels of one video are filled by the other), results bit-identical to the one-at-a-time "
+                    "run (checked in the run: `eager.identical_to_graph_path`, tools/concurrency_check.py)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -356,8 +356,8 @@ def main():
     # Independent (prompt, reference-video) samples are the unit of parallelism of this workload.  `--inflight`
     # of them can run concurrently inside one GPU, each on its own HIP stream with its own sampler (and graphs): the launch
     # sequence of one video leaves CUs idle in kernel tails and in the small 16x16 / 8x8-level kernels, which a second video
-    # fills (measured +7-9 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).  NOT the default:
-    # see the --inflight help.
+    # fills (measured +8-10 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).  Results are
+    # bit-identical to the one-at-a-time run since the library is built without packed-fp32 VALU code (csrc/temporal.hip).
     NF = max(1, min(args.inflight, args.steps))
     streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     smps = [smp] + [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
@@ -371,37 +371,31 @@ def main():
                                                 for k in range(NF - 1)]
 
     def run_videos(nvideos, step_events=None):
-        """nvideos videos, NF at a time: step i of every in-flight video is issued before step i + 1 of any"""
+        """nvideos videos, NF at a time (motionclone_amd.sampler.sample_interleaved)"""
         last = None
         done = 0
-        cur = torch.cuda.current_stream(dev)
+        pending = {}
+
+        def on_step(k, i, enter):
+            if step_events is None:
+                return
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            if enter:
+                pending[k] = ev
+            else:
+                step_events.append((i < G_STEPS, pending.pop(k), ev))
+
         while done < nvideos:
             k_act = min(NF, nvideos - done)
-            for st in streams[:k_act]:
-                st.wait_stream(cur)
-            xs, reps = [None] * k_act, [None] * k_act
-            for k in range(k_act):
-                la, tx, vd, nz = lane_inputs[k]
-                with torch.cuda.stream(streams[k]):
-                    reps[k] = smps[k].engine.prepare_representation(smps[k].extract(vd, nz, tx[0:1], add_noise_step=400, ctrl=ctrl))
-                    xs[k] = la
-            for i in range(N_STEPS):
-                for k in range(k_act):
-                    with torch.cuda.stream(streams[k]):
-                        if step_events is not None:
-                            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                            e0.record()
-                        xs[k] = smps[k].step(xs[k], i, lane_inputs[k][1], reps[k], ctrl=ctrl)
-                        if step_events is not None:
-                            e1.record()
-                            step_events.append((i < G_STEPS, e0, e1))
-            for st in streams[:k_act]:
-                cur.wait_stream(st)
+            xs = sample_interleaved(smps[:k_act], lane_inputs[:k_act], streams[:k_act], add_noise_step=400, ctrl=ctrl,
+                                    on_step=on_step)
             last = xs[0]
             done += k_act
         return last
 
-    run_videos(max(NF, args.warmup) if use_graphs else args.warmup * 1)   # every lane's first pass captures: never timed
+    warm_videos = max(NF, args.warmup)     # every lane's first pass captures its graphs / fills its allocator pool: never timed
+    run_videos(warm_videos)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -506,6 +500,7 @@ def main():
             # SURVEY.md 8(f) rank 1, measured OUTSIDE the timed region (BASELINE's metric is the UNet loop): the VAE calls
             # around it - decode_latents of the sampled video and the encode of the reference video - on the same kernels
             "vae": vae_info,
+            "warmup_videos_run": warm_videos,
             "graphs": graph_info,
             "eager": eager_info,
         }

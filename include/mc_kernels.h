@@ -186,6 +186,16 @@ int mc_cfg_ddim_step_f16(const void* eps_c, const void* eps_u, int ld, const voi
                          void* out, void* eps_out, float cfg, float sqrt_a_t, float sqrt_1m_a_t,
                          float sqrt_a_prev, float sqrt_1m_a_prev, float score_coef, int CL, int F, int HW,
                          void* stream);
+/* schedule_customized_step with every branch (motionclone_functions.py:285-409): prediction_type epsilon / sample /
+ * v_prediction, clip_sample, use_clipped_model_output, eta > 0 with variance noise, the score term, return_middle.
+ *   x0  = x0_s * sample + x0_m * model_output, clamped to [-clip, clip] if clip > 0;
+ *   eps = ep_s * sample + ep_m * model_output, or (sample - sqrt_a x0) / sqrt_b if rederive;   -> eps_out (un-guided)
+ *   eps' = eps - score_coef * score;   prev = c_x0 x0 + c_dir eps' + c_noise noise.
+ * All tensors n contiguous elements in one common layout; fp16 except score (fp32); score / noise / each output may be NULL. */
+int mc_ddim_step_general_f16(const void* sample, const void* model_output, const float* score, const void* noise,
+                             void* prev, void* x0_out, void* eps_out, long n, float x0_s, float x0_m, float ep_s,
+                             float ep_m, float clip, int rederive, float sqrt_a, float sqrt_b, float score_coef,
+                             float c_x0, float c_dir, float c_noise, void* stream);
 
 #ifdef __cplusplus
 }

@@ -41,7 +41,11 @@ def _deps():
 def build_hip(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link csrc/libmotionclone_hip.so."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only"]
+    # -fno-slp-vectorize: no packed fp32 VALU instructions (v_pk_fma_f32 ...).  Measured: the temporal-attention backward was
+    # not bit-reproducible with them when MFMA waves of another stream shared its SIMDs (csrc/temporal.hip header), and the
+    # library is 1.4 % faster end to end without them (a v_pk_fma_f32 costs two v_fma_f32 issue slots beside MFMAs anyway).
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+             "-fno-slp-vectorize"]
     stamp = _stamp(_deps(), " ".join(flags))
     stamp_file = HIP_LIB + ".stamp"
     if not force and os.path.exists(HIP_LIB) and os.path.exists(stamp_file):

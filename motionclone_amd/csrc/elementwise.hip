@@ -325,6 +325,34 @@ __global__ void cfg_ddim_kernel(const half_t* eps_c, const half_t* eps_u, int ld
     }
 }
 
+// schedule_customized_step in full (motionclone_functions.py:285-409): every branch is an affine map of
+// (sample, model_output, score, variance_noise), same [B, C, F, H, W] layout for all operands
+struct DdimGeneral {
+    float x0_s, x0_m;       // pred_original_sample = x0_s * sample + x0_m * model_output        (:338-352, by prediction_type)
+    float ep_s, ep_m;       // pred_epsilon         = ep_s * sample + ep_m * model_output
+    float clip;             // > 0: clamp pred_original_sample to [-clip, clip]                   (:356-360)
+    int rederive;           // use_clipped_model_output: eps = (sample - sqrt_a * x0) / sqrt_b    (:367-369)
+    float sqrt_a, sqrt_b;
+    float score_coef;       // guidance_scale * sqrt(1 - alpha_t) (0 without a score)             (:375-383)
+    float c_x0, c_dir, c_noise;   // prev = c_x0 * x0 + c_dir * eps + c_noise * variance_noise    (:386-405)
+};
+__global__ void ddim_general_kernel(const half_t* sample, const half_t* mo, const float* score, const half_t* noise,
+                                    half_t* prev, half_t* x0_out, half_t* eps_out, DdimGeneral k, long total) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        float sv = (float)sample[i], mv = (float)mo[i];
+        float x0 = k.x0_s * sv + k.x0_m * mv;
+        float ep = k.ep_s * sv + k.ep_m * mv;
+        if (k.clip > 0.f) x0 = fminf(fmaxf(x0, -k.clip), k.clip);
+        if (k.rederive) ep = (sv - k.sqrt_a * x0) / k.sqrt_b;
+        if (eps_out) eps_out[i] = to_half(ep);                 // return_middle hands out the un-guided epsilon (:371-372)
+        if (score) ep -= k.score_coef * score[i];
+        float pv = k.c_x0 * x0 + k.c_dir * ep;
+        if (noise) pv += k.c_noise * (float)noise[i];
+        if (prev) prev[i] = to_half(pv);
+        if (x0_out) x0_out[i] = to_half(x0);
+    }
+}
+
 static inline int ew_blocks(long total) {
     long b = (total + 255) / 256;
     if (b > 8192) b = 8192;
@@ -406,6 +434,20 @@ extern "C" int mc_cfg_ddim_step_f16(const void* eps_c, const void* eps_u, int ld
     MC_LAUNCH(cfg_ddim_kernel, dim3(ew_blocks((long)CL * F * HW)), dim3(256), 0, (hipStream_t)stream,
               (const half_t*)eps_c, (const half_t*)eps_u, ld, (const half_t*)x, score, (half_t*)out,
               (half_t*)eps_out, k, CL, F, HW);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+extern "C" int mc_ddim_step_general_f16(const void* sample, const void* model_output, const float* score,
+                                        const void* noise, void* prev, void* x0_out, void* eps_out, long n,
+                                        float x0_s, float x0_m, float ep_s, float ep_m, float clip, int rederive,
+                                        float sqrt_a, float sqrt_b, float score_coef, float c_x0, float c_dir,
+                                        float c_noise, void* stream) {
+    if (n <= 0 || !sample || !model_output || (!prev && !x0_out && !eps_out)) return MC_ERR_SHAPE;
+    if (rederive && sqrt_b <= 0.f) return MC_ERR_SHAPE;
+    DdimGeneral k{x0_s, x0_m, ep_s, ep_m, clip, rederive, sqrt_a, sqrt_b, score_coef, c_x0, c_dir, c_noise};
+    MC_LAUNCH(ddim_general_kernel, dim3(ew_blocks(n)), dim3(256), 0, (hipStream_t)stream, (const half_t*)sample,
+              (const half_t*)model_output, score, (const half_t*)noise, (half_t*)prev, (half_t*)x0_out,
+              (half_t*)eps_out, k, n);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 

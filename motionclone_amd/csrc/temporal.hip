@@ -22,11 +22,13 @@ namespace mc {
 
 // K = 16 step as the K = 32 instruction with the upper k-slots zero (the legacy v_mfma_f32_16x16x16_f16 returned wrong sums
 // behind K = 32 steps on one accumulator in attention.hip; it is not used in this library).
-// OPEN ISSUE (round 2, tools/race_hunt*.py): tattn_bwd_kernel is bit-reproducible on its own and under concurrent GEMM /
-// LayerNorm / copy kernels, but whole (pixel, head) units of dq / dk change by ~1 % when spatial-attention (or 128x128 GEMM)
-// workgroups of ANOTHER STREAM share its CUs.  Ruled out: legacy MFMA shape, interleaved accumulator chains, AGPR
-// accumulators, missing MFMA wait states, the ds_bpermute shuffles, out-of-bounds writes of the co-resident kernels.
-// Until it is understood, the sampler runs one video at a time per GPU (bench.py --inflight 1).
+// Round-2 finding (tools/race_dump.py, race_variants.py; profiles/r02_concurrency_and_determinism.md): with hipcc's SLP
+// vectoriser on, the softmax-backward arithmetic of tattn_bwd_kernel became v_pk_mul / v_pk_fma / v_pk_add_f32 chains, and the
+// row term D = sum(P * dP) of 30-60 of 32768 (pixel, head) units came out with one lane group's contribution missing whenever
+// MFMA-heavy waves of ANOTHER stream (flash attention, 128x128 GEMM) shared the SIMD; inputs and every other intermediate were
+// bit-identical, the exchange instruction (ds_bpermute / v_permlane*_swap) and SGPR operands made no difference, and the same
+// source built with -fno-slp-vectorize (no packed fp32 VALU instructions) is bit-stable.  The library is built that way
+// (build.py); it is also 1.4 % faster end to end.
 __device__ __forceinline__ f32x4 mfma16z(half4_t a, half4_t b, f32x4 c) { return mfma16k32(cat4(a, zero4()), cat4(b, zero4()), c); }
 
 struct TParams {
@@ -82,17 +84,8 @@ __device__ __forceinline__ half4_t t_col_frag(const half_t* x, int ld, const TPa
     return r;
 }
 
-__device__ __forceinline__ float group_max(float v) {  // across the 4 lane groups sharing lane&15
-    v = fmaxf(v, shfl_xor(v, 16));
-    return fmaxf(v, shfl_xor(v, 32));
-}
-__device__ __forceinline__ float group_sum(float v) {
-    v += shfl_xor(v, 16);
-    return v + shfl_xor(v, 32);
-}
-
-// Exchange variants for the determinism hunt (tools/race_dump.py): 0 = ds_bpermute (as above), 2 = ds_bpermute with a full
-// lgkmcnt(0) drain behind every exchange, 3 = v_permlane16_swap / v_permlane32_swap (VALU only, no LDS crossbar)
+// exchanges across the 4 lane groups sharing lane&15: v_permlane16_swap / v_permlane32_swap (gfx950; VALU only, no trip
+// through the LDS crossbar as with ds_bpermute).  swap(a, a) leaves {rows 0,0,2,2} / {rows 1,1,3,3} resp. {lo,lo} / {hi,hi}.
 #ifndef MC_EMU
 __device__ __forceinline__ float xchg16(float v) {   // v[lane ^ 16]
     unsigned u = __float_as_uint(v);
@@ -104,27 +97,17 @@ __device__ __forceinline__ float xchg32(float v) {   // v[lane ^ 32]
     auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
     return __uint_as_float((threadIdx.x & 32) ? r[0] : r[1]);
 }
-#endif
-template <int VAR>
-__device__ __forceinline__ float group_x(float v, int m) {
-#ifndef MC_EMU
-    if constexpr (VAR == 3) return m == 16 ? xchg16(v) : xchg32(v);
-    float r = shfl_xor(v, m);
-    if constexpr (VAR == 2) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(r));
-    return r;
 #else
-    return shfl_xor(v, m);
+__device__ inline float xchg16(float v) { return shfl_xor(v, 16); }
+__device__ inline float xchg32(float v) { return shfl_xor(v, 32); }
 #endif
+__device__ __forceinline__ float group_max(float v) {
+    v = fmaxf(v, xchg16(v));
+    return fmaxf(v, xchg32(v));
 }
-template <int VAR>
-__device__ __forceinline__ float group_max_v(float v) {
-    v = fmaxf(v, group_x<VAR>(v, 16));
-    return fmaxf(v, group_x<VAR>(v, 32));
-}
-template <int VAR>
-__device__ __forceinline__ float group_sum_v(float v) {
-    v += group_x<VAR>(v, 16);
-    return v + group_x<VAR>(v, 32);
+__device__ __forceinline__ float group_sum(float v) {
+    v += xchg16(v);
+    return v + xchg32(v);
 }
 
 // Scores of query tile tq against all key tiles, transposed orientation:
@@ -314,9 +297,6 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
     TUnit u = t_unit(P);
     if (!u.live) return;
     const long unit = ((long)u.b * P.HW + u.p) * P.heads + u.h;
-#ifndef MC_EMU
-    if constexpr (VAR == 4) asm volatile("" : "+v"(seed_coef));   // hunt: keep the coefficient out of SGPR operands
-#endif
 
     // S (q rows), S^T (kv rows), dP, dP^T accumulated over the head dimension
     f32x4 s[NT][NT], sT[NT][NT], dp[NT][NT], dpT[NT][NT];  // [tq][tk]
@@ -378,13 +358,13 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
                 sT[tq][tk][i] = kv < P.F ? sT[tq][tk][i] * P.scale : -INFINITY;
                 m = fmaxf(m, sT[tq][tk][i]);
             }
-        m = group_max_v<VAR>(m);
+        m = group_max(m);
         float l = 0.f;
 #pragma unroll
         for (int tk = 0; tk < NT; ++tk)
 #pragma unroll
             for (int i = 0; i < 4; ++i) l += expf(sT[tq][tk][i] - m);
-        l = group_sum_v<VAR>(l);
+        l = group_sum(l);
         mq[tq] = m;
         lq[tq] = l;
         // P^T, total dP^T (attention path + guidance seed), D = sum_kv P * dP
@@ -401,7 +381,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
                 dpT[tq][tk][i] = d;
                 dsum += pv * d;
             }
-        Dq[tq] = group_sum_v<VAR>(dsum);
+        Dq[tq] = group_sum(dsum);
     }
 
     // dS^T = P^T * (dP^T - D) (fp16 B operands); and the q-row orientation via lane broadcasts
@@ -517,24 +497,6 @@ static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* d
                       dq, dk, dv, ldg, ri, rv, coef, g_tattn_debug_buf);
             return;
         }
-#ifndef MC_EMU
-        const char* var = getenv("MC_TATTN_VARIANT");
-        if (var && var[0] == '2') {
-            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
-                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
-            return;
-        }
-        if (var && var[0] == '4') {
-            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 4>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
-                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
-            return;
-        }
-        if (var && var[0] == '3') {
-            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 3>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
-                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
-            return;
-        }
-#endif
     }
     MC_LAUNCH((tattn_bwd_kernel<NT, DT>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo, dq, dk,
               dv, ldg, ri, rv, coef, (float*)nullptr);

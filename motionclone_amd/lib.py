@@ -61,6 +61,7 @@ SIGNATURES = {
     "mc_timestep_embed_f16": [P, P, I, I, P],
     "mc_silu_f16": [P, P, L, P],
     "mc_cfg_ddim_step_f16": [P, P, I, P, P, P, P, F, F, F, F, F, F, I, I, I, P],
+    "mc_ddim_step_general_f16": [P, P, P, P, P, P, P, L, F, F, F, F, F, I, F, F, F, F, F, F, P],
 }
 
 ERRORS = {-1: "bad shape / stride / alignment", -2: "unsupported size", -3: "kernel launch failed"}

@@ -403,6 +403,30 @@ def silu(x):
     return out
 
 
+def ddim_step_general(sample, model_output, score, noise, coef, want_prev=True, want_x0=True, want_eps=False):
+    """mc_ddim_step_general_f16: every branch of schedule_customized_step as one elementwise pass.  All tensors share one
+    layout ([B, C, F, H, W] as the reference holds them); `coef` = dict(x0_s, x0_m, ep_s, ep_m, clip, rederive, sqrt_a,
+    sqrt_b, score_coef, c_x0, c_dir, c_noise).  Returns (prev, x0, eps) with None for outputs not asked for."""
+    sample = sample.contiguous().half()
+    model_output = model_output.contiguous().half()
+    if tuple(model_output.shape) != tuple(sample.shape):
+        raise ValueError("ddim_step_general: sample %s vs model_output %s" % (tuple(sample.shape), tuple(model_output.shape)))
+    for name, t in (("score", score), ("variance_noise", noise)):
+        if t is not None and tuple(t.shape) != tuple(sample.shape):
+            raise ValueError("ddim_step_general: %s %s vs sample %s" % (name, tuple(t.shape), tuple(sample.shape)))
+    score = None if score is None else score.float().contiguous()
+    noise = None if noise is None else noise.contiguous().half()
+    prev = torch.empty_like(sample) if want_prev else None
+    x0 = torch.empty_like(sample) if want_x0 else None
+    eps = torch.empty_like(sample) if want_eps else None
+    c = coef
+    lib.call("mc_ddim_step_general_f16", _p(sample), _p(model_output), _p(score), _p(noise), _p(prev), _p(x0), _p(eps),
+             sample.numel(), float(c["x0_s"]), float(c["x0_m"]), float(c["ep_s"]), float(c["ep_m"]), float(c.get("clip", 0.0)),
+             int(bool(c.get("rederive", False))), float(c["sqrt_a"]), float(c["sqrt_b"]), float(c.get("score_coef", 0.0)),
+             float(c["c_x0"]), float(c["c_dir"]), float(c.get("c_noise", 0.0)), _stream(sample))
+    return prev, x0, eps
+
+
 def cfg_ddim_step(eps_c, eps_u, x, score, cfg, a_t, a_prev, score_coef, want_eps=False):
     """x, score: [1, CL, F, H, W]; eps_*: channels-last token matrices (first CL columns)."""
     B, CL, F, H, W = x.shape

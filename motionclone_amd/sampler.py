@@ -185,3 +185,36 @@ class MotionCloneSampler:
             if progress is not None:
                 progress(i)
         return latents
+
+
+def sample_interleaved(samplers, jobs, streams, add_noise_step=400, ctrl=None, on_step=None):
+    """Several independent videos in flight on one GPU (examples are the unit of parallelism).
+
+    `jobs[k] = (latents, text [2,77,768], reference_video_latents, extraction_noise)` runs on `samplers[k]` / `streams[k]`
+    (one sampler per lane: each owns its hipGraphs and static buffers); step i of every job is issued before step i + 1
+    of any, so the kernels of the lanes interleave on the device and fill each other's tails.  Results are bit-identical
+    to running the jobs one after the other (tools/concurrency_check.py).  `on_step(k, i, enter)` is called around every
+    step inside the lane's stream context (bench.py records its events there).  Returns the final latents per job."""
+    n = len(jobs)
+    if n > len(samplers) or n > len(streams):
+        raise ValueError("sample_interleaved: %d jobs for %d samplers / %d streams" % (n, len(samplers), len(streams)))
+    cur = torch.cuda.current_stream(jobs[0][0].device)
+    for st in streams[:n]:
+        st.wait_stream(cur)
+    xs, reps = [None] * n, [None] * n
+    for k, (lat, text, vid, noise) in enumerate(jobs):
+        with torch.cuda.stream(streams[k]):
+            rep = samplers[k].extract(vid, noise, text[0:1], add_noise_step=add_noise_step, ctrl=ctrl)
+            reps[k] = samplers[k].engine.prepare_representation(rep)
+            xs[k] = lat
+    for i in range(len(samplers[0].timesteps)):
+        for k in range(n):
+            with torch.cuda.stream(streams[k]):
+                if on_step is not None:
+                    on_step(k, i, True)
+                xs[k] = samplers[k].step(xs[k], i, jobs[k][1], reps[k], ctrl=ctrl)
+                if on_step is not None:
+                    on_step(k, i, False)
+    for st in streams[:n]:
+        cur.wait_stream(st)
+    return xs

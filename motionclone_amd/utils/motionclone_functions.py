@@ -201,23 +201,70 @@ def schedule_customized_step(self, model_output, step_index: int, sample, eta: f
                              use_clipped_model_output: bool = False, generator=None, variance_noise=None,
                              return_dict: bool = True, score=None, guidance_scale=1.0, indices=None,
                              return_middle=False):
-    """:285-409 for the configuration the path uses (epsilon prediction, eta = 0, no clipping): one fused kernel."""
+    """:285-409, every branch: prediction_type epsilon / sample / v_prediction, clip_sample, use_clipped_model_output,
+    eta > 0 (variance noise drawn like randn_tensor or passed in), the score term (optionally on a batch subset
+    `indices`), return_middle.  All of it is an affine map of (sample, model_output, score, noise): one elementwise
+    kernel (mc_ddim_step_general_f16) in the tensors' own [B, C, F, H, W] layout; the host only derives the scalars."""
     if self.num_inference_steps is None:
         raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
-    if eta != 0.0 or use_clipped_model_output or indices is not None or return_middle:
-        raise NotImplementedError("only the eta = 0 DDIM update used by single_step_video is built")
+    if model_output.shape[1] == sample.shape[1] * 2 and getattr(self, "variance_type", None) in ["learned", "learned_range"]:
+        model_output, _ = torch.split(model_output, sample.shape[1], dim=1)      # :319-322 (IF models)
+    cfg = self.config
     t = int(self.timesteps[step_index])
     t_prev = int(self.timesteps[step_index + 1]) if step_index + 1 < len(self.timesteps) else -1
     a_t = float(self.alphas_cumprod[t])
     a_prev = float(self.alphas_cumprod[t_prev]) if t_prev >= 0 else float(self.final_alpha_cumprod)
-    eps_cl = ops.latent_to_cl(model_output.half(), 8)
-    coef = float(guidance_scale) * (1.0 - a_t) ** 0.5 if (score is not None and guidance_scale > 0.0) else 0.0
-    prev, eps = ops.cfg_ddim_step(eps_cl, eps_cl, sample.half(), None if score is None else score.float(), 0.0, a_t,
-                                  a_prev, coef, want_eps=True)
+    sa, sb = a_t ** 0.5, (1.0 - a_t) ** 0.5
+    ptype = getattr(cfg, "prediction_type", "epsilon")
+    if ptype == "epsilon":
+        co = dict(x0_s=1.0 / sa, x0_m=-sb / sa, ep_s=0.0, ep_m=1.0)
+    elif ptype == "sample":
+        co = dict(x0_s=0.0, x0_m=1.0, ep_s=1.0 / sb, ep_m=-sa / sb)
+    elif ptype == "v_prediction":
+        co = dict(x0_s=sa, x0_m=-sb, ep_s=sb, ep_m=sa)
+    else:
+        raise ValueError(f"prediction_type given as {ptype} must be one of `epsilon`, `sample`, or `v_prediction`")
+    if getattr(cfg, "thresholding", False):
+        raise NotImplementedError("dynamic thresholding (per-sample quantile of |x0|) is not built; the path's scheduler "
+                                  "config has thresholding = False")
+    clip = float(getattr(cfg, "clip_sample_range", 1.0)) if getattr(cfg, "clip_sample", False) else 0.0
+    variance = (1.0 - a_prev) / (1.0 - a_t) * (1.0 - a_t / a_prev)               # _get_variance(timestep, prev_timestep)
+    std = float(eta) * max(variance, 0.0) ** 0.5
+    guided = score is not None and guidance_scale > 0.0
+    co.update(clip=clip, rederive=bool(use_clipped_model_output), sqrt_a=sa, sqrt_b=sb,
+              score_coef=float(guidance_scale) * sb if guided else 0.0,
+              c_x0=a_prev ** 0.5, c_dir=max(1.0 - a_prev - std * std, 0.0) ** 0.5, c_noise=std)
+
+    if score is not None and return_middle:                                       # :371-372
+        _, x0, eps = ops.ddim_step_general(sample, model_output, None, None, co, want_prev=False, want_eps=True)
+        return eps.to(model_output.dtype), self.alphas_cumprod[t], \
+            (self.alphas_cumprod[t_prev] if t_prev >= 0 else self.final_alpha_cumprod), x0.to(sample.dtype)
+
+    score_full = None
+    if guided:
+        if indices is not None:
+            sel = model_output[indices]
+            assert sel.shape == score.shape, "pred_epsilon[indices].shape != score.shape"
+            score_full = torch.zeros(model_output.shape, dtype=torch.float32, device=model_output.device)
+            score_full[indices] = score.float()                                   # data movement only; arithmetic in the kernel
+        else:
+            assert model_output.shape == score.shape
+            score_full = score.float()
+    if eta > 0:
+        if variance_noise is not None and generator is not None:
+            raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"
+                             " `variance_noise` stays `None`.")
+        if variance_noise is None:                                               # randn_tensor(shape, generator, device, dtype)
+            gdev = generator.device if generator is not None else model_output.device
+            variance_noise = torch.randn(model_output.shape, generator=generator, device=gdev,
+                                         dtype=model_output.dtype).to(model_output.device)
+    else:
+        variance_noise = None
+    prev, x0, _ = ops.ddim_step_general(sample, model_output, score_full, variance_noise, co, want_x0=return_dict)
+    prev = prev.to(sample.dtype)
     if not return_dict:
         return (prev,)
-    x0 = (sample.float() - (1 - a_t) ** 0.5 * model_output.float()) / a_t ** 0.5
-    return prev, x0.to(sample.dtype), a_prev
+    return prev, x0.to(sample.dtype), (self.alphas_cumprod[t_prev] if t_prev >= 0 else self.final_alpha_cumprod)
 
 
 def schedule_set_timesteps(self, num_inference_steps: int, guidance_steps: int = 0, guiduance_scale: float = 0.0,

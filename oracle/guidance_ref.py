@@ -52,6 +52,48 @@ def ddim_step(acp, timesteps, step_index, eps, sample, score=None, guidance_scal
     return a_prev ** 0.5 * x0 + (1 - a_prev) ** 0.5 * eps
 
 
+def ddim_step_general(acp, final_acp, timesteps, step_index, model_output, sample, prediction_type="epsilon",
+                      clip_sample=False, clip_sample_range=1.0, eta=0.0, use_clipped_model_output=False,
+                      variance_noise=None, score=None, guidance_scale=1.0, indices=None, return_middle=False):
+    """schedule_customized_step with all of its branches (motionclone_functions.py:285-409), fp32.
+    Returns (prev_sample, pred_original_sample, alpha_prod_t_prev) or, for return_middle with a score (:371-372),
+    (pred_epsilon, alpha_prod_t, alpha_prod_t_prev, pred_original_sample)."""
+    t = int(timesteps[step_index])
+    t_prev = int(timesteps[step_index + 1]) if step_index + 1 < len(timesteps) else -1      # :327
+    a_t = acp[t]
+    a_prev = acp[t_prev] if t_prev >= 0 else final_acp                                     # :330-331
+    b_t = 1 - a_t
+    if prediction_type == "epsilon":                                                       # :337-346
+        x0 = (sample - b_t ** 0.5 * model_output) / a_t ** 0.5
+        eps = model_output
+    elif prediction_type == "sample":
+        x0 = model_output
+        eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+    elif prediction_type == "v_prediction":
+        x0 = a_t ** 0.5 * sample - b_t ** 0.5 * model_output
+        eps = a_t ** 0.5 * model_output + b_t ** 0.5 * sample
+    else:
+        raise ValueError(prediction_type)
+    if clip_sample:                                                                        # :356-360
+        x0 = x0.clamp(-clip_sample_range, clip_sample_range)
+    variance = (1 - a_prev) / (1 - a_t) * (1 - a_t / a_prev)                               # _get_variance, :364
+    std = eta * variance ** 0.5
+    if use_clipped_model_output:                                                           # :367-369
+        eps = (sample - a_t ** 0.5 * x0) / b_t ** 0.5
+    if score is not None and return_middle:                                                # :371-372
+        return eps, a_t, a_prev, x0
+    if score is not None and guidance_scale > 0.0:                                         # :375-383
+        if indices is not None:
+            eps = eps.clone()
+            eps[indices] = eps[indices] - guidance_scale * (1 - a_t) ** 0.5 * score
+        else:
+            eps = eps - guidance_scale * (1 - a_t) ** 0.5 * score
+    prev = a_prev ** 0.5 * x0 + (1 - a_prev - std ** 2) ** 0.5 * eps                       # :386-389
+    if eta > 0:                                                                            # :391-405
+        prev = prev + std * variance_noise
+    return prev, x0, a_prev
+
+
 # ---- guidance read-out --------------------------------------------------------------------------------
 def temp_attn_prob(record, heads):
     """get_temp_attn_prob (motionclone_functions.py:260-283): softmax(scale q_h k_h^T) per hooked module,
