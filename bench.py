@@ -37,17 +37,18 @@ def gemm_kernel_name(mode, M, N, K=0):
     """Which kernel instance mc_gemm_f16 picks in auto mode (mirrors the heuristic in csrc/gemm.hip)."""
     modes = {ops.DENSE: "DENSE", ops.CONV_S1: "CONV_S1", ops.CONV_S2: "CONV_S2", ops.CONV_UP: "CONV_UP",
              ops.TCONV_S2: "TCONV_S2"}
-    plan = lib.load().mc_gemm_splitk_plan(M, N, K, mode) if K else 1
+    sh = ops._GEMM_SHARE
+    plan = lib.load().mc_gemm_splitk_plan(M, N, K, mode | (sh << 8)) if K else 1
     if mode == ops.DENSE and K == 320 and N % 32 == 0 and (M >= 98304 or (M >= 32768 and N >= 640)):
         return "gemm4_kernel<K=320 streaming>"
     if plan > 1:
         return "gemm3_kernel<%s,%s> split-K + reduce" % (modes[mode], "256,320,4,2" if (plan >> 8) == 1 else "128,320,2,2")
     if N % 320 == 0:
-        if ((M + 255) // 256) * (N // 320) >= 224:
+        if ((M + 255) // 256) * (N // 320) >= (224 >> sh):
             return "gemm3_kernel<%s,256,320,4,2>" % modes[mode]
-        if ((M + 127) // 128) * (N // 320) >= 192:
+        if ((M + 127) // 128) * (N // 320) >= (192 >> sh):
             return "gemm3_kernel<%s,128,320,2,2>" % modes[mode]
-    if ((M + 127) // 128) * ((N + 127) // 128) < 256:
+    if ((M + 127) // 128) * ((N + 127) // 128) < (256 >> sh):
         return "gemm2_kernel<%s,64,64,2>" % modes[mode]
     return "gemm2_kernel<%s,128,128,2>" % modes[mode]
 
@@ -359,6 +360,7 @@ def main():
     # fills (measured +8-10 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).  Results are
     # bit-identical to the one-at-a-time run since the library is built without packed-fp32 VALU code (csrc/temporal.hip).
     NF = max(1, min(args.inflight, args.steps))
+    ops.set_gemm_share(NF)      # every launch of this process, timed region and probe alike (tile / split-K choice only)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     smps = [smp] + [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                                        num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE,

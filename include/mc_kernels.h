@@ -52,11 +52,14 @@ long mc_workspace_bytes_tattn_loss(int B, int HW, int heads);
  * A2 (optional) supplies channels [c1, ctot) - the skip concat of unet_blocks.py:634,740.
  * K = ctot (dense) or 9*ctot (conv; k = (c/64)*576 + tap*64 + c%64: channel-tile major, tap minor).
  * K, ctot, c1 multiples of 64; N, ldc multiples of 4.
- * flags: bits 0-7 block tile edge (0 = auto, 64, 128); 0x100 = force the first-generation kernel;
+ * flags: bits 0-7 block tile edge (0 = auto, 64, 128); 0x100 = (removed) first-generation kernel -> unsupported;
  *        0x200 = fused GEGLU epilogue: W rows interleaved (h_j, gate_j), C gets N/2 columns h_j * gelu(gate_j);
  *        0x400 = 3-stage staging ring (128/64 tiles); 0x800 = mode 2 with padding only right / bottom
  *        (diffusers Downsample2D(padding=0): F.pad(x, (0,1,0,1)) + stride-2 conv, the VAE encoder);
- *        bits 12-15 = large-tile geometry of gemm3.hip (0 = automatic). */
+ *        bits 12-15 = large-tile geometry of gemm3.hip (0 = automatic; 10 = the K = 320 streaming kernel gemm4.hip);
+ *        bits 16-19 = gemm4: workgroups per 256-row block (0 = automatic);
+ *        bits 20-21 = share: 2^share independent launch sequences are in flight on other streams, so the automatic
+ *        tile / split-K choice targets 256 >> share CUs (mc_gemm_splitk_plan takes the same value in mode bits 8-9). */
 int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);

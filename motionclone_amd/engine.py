@@ -679,24 +679,60 @@ class ControlNetEngine(UNet3DEngine):
             names += ["down_blocks.%d.resnets.%d." % (i, j) for j in range(L)]
         return names + ["mid_block.resnets.0.", "mid_block.resnets.1."]
 
+    def _cond_embedding(self, cond, mask, F, H, W):
+        """controlnet_cond_embedding(cat(cond, mask)) + conv_in.bias (:516-527) as a token matrix [(f y x), C0].
+        latent_condition.yaml: one 3x3 conv on VAE latent + mask at latent resolution.  image_condition.yaml (scribble /
+        sketch): SparseControlNetConditioningEmbedding (:49-82) on pixels + mask at 8x the latent resolution - conv_in,
+        then (same-width, stride-2 widening) conv pairs down to the latent grid, SiLU after each, conv_out; every conv an
+        implicit GEMM on 64-padded channels-last rows (padding channels stay zero through SiLU).  Recomputed at every call,
+        as in the reference."""
+        w = self.w
+        cm = torch.cat([cond, mask], dim=1).to(torch.float16)
+        p = "controlnet_cond_embedding."
+        cin_b = w.vec("conv_in.bias")
+        if (p + "weight") in w.sd:
+            if tuple(cm.shape[2:]) != (F, H, W):
+                raise ValueError("latent condition %s does not match the sample grid %s" % (tuple(cm.shape), (F, H, W)))
+            bias = (w.vec(p + "bias") + cin_b).unsqueeze(0).contiguous()
+            e = ops.gemm(ops.latent_to_cl(cm, CIN_PAD), w.conv(p + "weight", CIN_PAD), bias=bias, mode=CONV_S1,
+                         geom=(H, W, H, W), m_out=F * H * W)
+        else:
+            Hs, Ws = cm.shape[3], cm.shape[4]
+            nblk = 0
+            while (p + "blocks.%d.weight" % nblk) in w.sd:
+                nblk += 1
+            if cm.shape[2] != F or (Hs >> (nblk // 2), Ws >> (nblk // 2)) != (H, W) or Hs % (1 << (nblk // 2)):
+                raise ValueError("pixel condition %s does not reduce to the sample grid %s" % (tuple(cm.shape), (F, H, W)))
+            x = ops.latent_to_cl(cm, 64)
+            names = [("conv_in.", 1)] + [("blocks.%d." % i, 2 if i % 2 else 1) for i in range(nblk)] + [("conv_out.", 1)]
+            for name, stride in names:
+                last = name == "conv_out."
+                cout = w.sd[p + name + "weight"].shape[0]
+                Ho, Wo = (Hs, Ws) if stride == 1 else (Hs // 2, Ws // 2)
+                rows, cpad = F * Ho * Wo, (cout + 63) // 64 * 64
+                buf = (torch.zeros if cpad != cout else torch.empty)((rows, cpad), dtype=torch.float16, device=self.dev)
+                b = w.vec(p + name + "bias")
+                ops.gemm(x, w.conv(p + name + "weight", pad_cin=x.shape[1]),
+                         bias=((b + cin_b) if last else b).unsqueeze(0).contiguous(),
+                         mode=CONV_S1 if stride == 1 else CONV_S2, geom=(Hs, Ws, Ho, Wo), m_out=rows, out=buf[:, :cout])
+                x = buf if last else ops.silu(buf)
+                Hs, Ws = Ho, Wo
+            e = x
+        return e
+
     @ops.scoped
     def forward(self, sample_shape, t, text, cond, mask, conditioning_scale=1.0):
-        """sample_shape = (B, 4, F, H, W); cond [1, Cc, F, H, W] latent condition (zeros on unconditioned frames),
-        mask [1, 1, F, H, W]; text [B, n, dim] -> (list of 12 residual token matrices [(b f y x), C], mid residual)"""
+        """sample_shape = (B, 4, F, H, W); cond [1, Cc, F, H, W] latent condition (or [1, 3, F, 8H, 8W] pixels for the
+        scribble embedding; zeros on unconditioned frames), mask [1, 1, F, ...] at the condition's resolution;
+        text [B, n, dim] -> (list of 12 residual token matrices [(b f y x), C], mid residual)"""
         cfg, w = self.cfg, self.w
-        if "controlnet_cond_embedding.weight" not in w.sd:
-            raise NotImplementedError("only the simplified (latent) condition embedding of "
-                                      "configs/sparsectrl/latent_condition.yaml is built")
         B, _, F, H, W = sample_shape
         L = cfg["layers_per_block"]
         geo = Geo(B, F, H, W)
         n_text = text.shape[1]
         text2d = text.reshape(B * n_text, text.shape[2]).contiguous()
         tb_all = self._time_bias(t, B, text)
-        cm = torch.cat([cond, mask], dim=1).to(torch.float16)
-        bias = (w.vec("controlnet_cond_embedding.bias") + w.vec("conv_in.bias")).unsqueeze(0).contiguous()
-        e = ops.gemm(ops.latent_to_cl(cm, CIN_PAD), w.conv("controlnet_cond_embedding.weight", CIN_PAD), bias=bias,
-                     mode=CONV_S1, geom=(H, W, H, W), m_out=F * H * W)
+        e = self._cond_embedding(cond, mask, F, H, W)
         x = torch.cat([e] * B, dim=0) if B > 1 else e     # the same condition for every batch element
         feats = [x]
         for i in range(4):

@@ -1,6 +1,7 @@
 """Drop-in `SparseControlNetModel` (reference motionclone/models/sparse_controlnet.py:85-587) backed by
-`ControlNetEngine`: same constructor / `from_unet` / state-dict keys / `forward` arguments for the configuration of
-configs/sparsectrl/latent_condition.yaml (i2v_rgb).  `forward` returns the 12 down residuals and the mid residual as
+`ControlNetEngine`: same constructor / `from_unet` / state-dict keys / `forward` arguments for the configurations of
+configs/sparsectrl/latent_condition.yaml (i2v_rgb: VAE-latent condition, one-conv embedding) and
+configs/sparsectrl/image_condition.yaml (i2v_sketch: pixel-space condition through SparseControlNetConditioningEmbedding).  `forward` returns the 12 down residuals and the mid residual as
 channels-last token matrices, which `UNet3DConditionModel.forward` and the sampler consume directly."""
 import torch
 from torch import nn
@@ -16,12 +17,12 @@ class SparseControlNetModel(nn.Module):
                  norm_num_groups=32, norm_eps=1e-5, use_motion_module=True, motion_module_resolutions=(1, 2, 4, 8),
                  motion_module_mid_block=False, motion_module_type="Vanilla", motion_module_kwargs=None,
                  concate_conditioning_mask=True, use_simplified_condition_embedding=False,
-                 set_noisy_sample_input_to_zero=False, **unused):
+                 set_noisy_sample_input_to_zero=False, conditioning_embedding_out_channels=(16, 32, 96, 256), **unused):
         super().__init__()
         mk = dict(motion_module_kwargs or {})
-        if not (use_simplified_condition_embedding and set_noisy_sample_input_to_zero and concate_conditioning_mask):
-            raise NotImplementedError("only configs/sparsectrl/latent_condition.yaml (simplified latent condition, zeroed "
-                                      "noisy input) is built; the scribble pyramid of image_condition.yaml is not")
+        if not (set_noisy_sample_input_to_zero and concate_conditioning_mask):
+            raise NotImplementedError("both SparseCtrl configurations of the reference (configs/sparsectrl/*.yaml) zero the "
+                                      "noisy input and concatenate the conditioning mask; other combinations are not built")
         if mk.get("attention_block_types", ["Temporal_Self"]) != ["Temporal_Self"]:
             raise NotImplementedError("SparseCtrl motion modules use a single Temporal_Self attention")
         heads = num_attention_heads or attention_head_dim
@@ -33,10 +34,12 @@ class SparseControlNetModel(nn.Module):
                                   motion_pe_max_len=mk.get("temporal_position_encoding_max_len", 32))
         self.config = FrozenConfig(in_channels=in_channels, conditioning_channels=conditioning_channels,
                                    block_out_channels=tuple(block_out_channels), global_pool_conditions=False)
-        self.use_simplified_condition_embedding = True
+        self.use_simplified_condition_embedding = bool(use_simplified_condition_embedding)
         self.set_noisy_sample_input_to_zero = True
-        _build_tree(self, spec.controlnet_param_shapes(self.engine_config, conditioning_channels), self.engine_config,
-                    torch.float16)
+        _build_tree(self, spec.controlnet_param_shapes(self.engine_config, conditioning_channels,
+                                                       simplified=self.use_simplified_condition_embedding,
+                                                       embedding_channels=tuple(conditioning_embedding_out_channels)),
+                    self.engine_config, torch.float16)
         self._engine = None
         self._engine_key = None
 

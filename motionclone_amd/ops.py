@@ -73,6 +73,17 @@ def workspace(op, like, *dims):
 
 # ---- GEMM family ---------------------------------------------------------------------------------
 _SPLIT_PLAN = {}   # (M, N, K, mode) -> mc_gemm_splitk_plan, memoised: one ctypes round trip less per launch
+_GEMM_SHARE = 0    # log2 of the launch sequences kept in flight on separate streams (set_gemm_share)
+
+
+def set_gemm_share(lanes):
+    """Tell the GEMM tile / split-K choice how many independent launch sequences share the GPU (sample_interleaved:
+    one per video in flight).  A launch then only has to fill 1 / lanes of the CUs (mc_gemm_f16 flags bits 20-21).  The
+    choice changes fp32 summation order, not arithmetic: results are reproducible for a given setting."""
+    global _GEMM_SHARE
+    _GEMM_SHARE = 0 if lanes <= 1 else (1 if lanes < 4 else 2)
+    return _GEMM_SHARE
+
 
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
          rows_per_batch=0, tile=0, m_out=None, geglu=False, deep=False, cfg=0, splits=None,
@@ -100,7 +111,7 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
     flags = tile | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
-        | (0 if pad_front else 0x800) | (nsplit << 16)
+        | (0 if pad_front else 0x800) | (nsplit << 16) | (_GEMM_SHARE << 20)
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N
@@ -108,10 +119,10 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         if geglu or tile or deep or cfg:
             splits = 1
         else:
-            key = (M, N, K, mode, lib.is_emulated())
+            key = (M, N, K, mode, _GEMM_SHARE, lib.is_emulated())
             splits = _SPLIT_PLAN.get(key)
             if splits is None:
-                splits = _SPLIT_PLAN[key] = lib.load().mc_gemm_splitk_plan(M, N, K, mode)
+                splits = _SPLIT_PLAN[key] = lib.load().mc_gemm_splitk_plan(M, N, K, mode | (_GEMM_SHARE << 8))
             if splits > 1:      # plan = K ranges | (gemm3 geometry << 8)
                 flags |= (splits >> 8) << 12
                 splits &= 0xFF

@@ -193,7 +193,9 @@ def sample_interleaved(samplers, jobs, streams, add_noise_step=400, ctrl=None, o
     `jobs[k] = (latents, text [2,77,768], reference_video_latents, extraction_noise)` runs on `samplers[k]` / `streams[k]`
     (one sampler per lane: each owns its hipGraphs and static buffers); step i of every job is issued before step i + 1
     of any, so the kernels of the lanes interleave on the device and fill each other's tails.  Results are bit-identical
-    to running the jobs one after the other (tools/concurrency_check.py).  `on_step(k, i, enter)` is called around every
+    to running the jobs one after the other (tools/concurrency_check.py) under the same `ops.set_gemm_share` setting
+    (callers that keep 2 lanes busy set it to 2 once, before any graph is captured: the GEMM tile / split-K choice then
+    targets half of the CUs per launch, +3.6 % videos/min).  `on_step(k, i, enter)` is called around every
     step inside the lane's stream context (bench.py records its events there).  Returns the final latents per job."""
     n = len(jobs)
     if n > len(samplers) or n > len(streams):

@@ -121,15 +121,29 @@ def param_shapes(cfg):
     return s
 
 
-def controlnet_param_shapes(cfg, conditioning_channels=4):
-    """reference SparseControlNetModel keys (sparse_controlnet.py:150-314), latent-condition configuration"""
+def controlnet_param_shapes(cfg, conditioning_channels=4, simplified=True, embedding_channels=(16, 32, 96, 256)):
+    """reference SparseControlNetModel keys (sparse_controlnet.py:150-314): `simplified` = the one-conv latent condition
+    embedding of latent_condition.yaml (:181-184), else the pixel-space SparseControlNetConditioningEmbedding of
+    image_condition.yaml (:49-82,185-190; `conditioning_channels` counts the image channels, the mask adds one)"""
     ch = cfg["block_out_channels"]
     temb, xdim, L = ch[0] * 4, cfg["cross_attention_dim"], cfg["layers_per_block"]
     s = OrderedDict()
     s["conv_in.weight"] = (ch[0], cfg["in_channels"], 3, 3)
     s["conv_in.bias"] = (ch[0],)
-    s["controlnet_cond_embedding.weight"] = (ch[0], conditioning_channels + 1, 3, 3)
-    s["controlnet_cond_embedding.bias"] = (ch[0],)
+    if simplified:
+        s["controlnet_cond_embedding.weight"] = (ch[0], conditioning_channels + 1, 3, 3)
+        s["controlnet_cond_embedding.bias"] = (ch[0],)
+    else:
+        e = tuple(embedding_channels)
+        s["controlnet_cond_embedding.conv_in.weight"] = (e[0], conditioning_channels + 1, 3, 3)
+        s["controlnet_cond_embedding.conv_in.bias"] = (e[0],)
+        for i in range(len(e) - 1):
+            s["controlnet_cond_embedding.blocks.%d.weight" % (2 * i)] = (e[i], e[i], 3, 3)
+            s["controlnet_cond_embedding.blocks.%d.bias" % (2 * i)] = (e[i],)
+            s["controlnet_cond_embedding.blocks.%d.weight" % (2 * i + 1)] = (e[i + 1], e[i], 3, 3)
+            s["controlnet_cond_embedding.blocks.%d.bias" % (2 * i + 1)] = (e[i + 1],)
+        s["controlnet_cond_embedding.conv_out.weight"] = (ch[0], e[-1], 3, 3)
+        s["controlnet_cond_embedding.conv_out.bias"] = (ch[0],)
     s["time_embedding.linear_1.weight"] = (temb, ch[0])
     s["time_embedding.linear_1.bias"] = (temb,)
     s["time_embedding.linear_2.weight"] = (temb, temb)

@@ -66,11 +66,13 @@ def _sampler(pipe):
 
 @torch.no_grad()
 def obtain_motion_representation(self, generator=None, motion_representation_path: str = None, duration=None,
-                                 use_controlnet=False, video_latents=None, uncond_embeddings=None):
-    """:25-82.  `video_latents` / `uncond_embeddings` let synthetic inputs bypass decord / VAE / CLIP."""
+                                 use_controlnet=False, video_latents=None, uncond_embeddings=None, video_data=None):
+    """:25-82.  `video_latents` / `uncond_embeddings` let synthetic inputs bypass decord / VAE / CLIP (`video_data`
+    [F, 3, H, W] in [-1, 1]: the preprocessed frames, needed beside `video_latents` only by the pixel-condition ControlNet)."""
     cfg = self.input_config
     if video_latents is None:
-        video_data = video_preprocess(cfg.video_path, cfg.height, cfg.width, cfg.video_length, duration=duration)
+        if video_data is None:
+            video_data = video_preprocess(cfg.video_path, cfg.height, cfg.width, cfg.video_length, duration=duration)
         lat = self.vae.encode(video_data.to(self.vae.dtype).to(self.vae.device)).latent_dist.sample(None)
         video_latents = (self.vae.config.scaling_factor * lat).unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
     if uncond_embeddings is None:
@@ -80,11 +82,17 @@ def obtain_motion_representation(self, generator=None, motion_representation_pat
     noise = torch.randn(video_latents.shape, generator=generator, device=video_latents.device, dtype=video_latents.dtype)
     noisy = self.add_noise(step_t, video_latents, noise)
     down_res = mid_res = None
-    if use_controlnet:   # :46-72: condition = the reference video's own latent at image_index (simplified embedding)
+    if use_controlnet:   # :46-72: condition = the reference video's own frames at image_index
         idx = cfg.image_index
-        cond = torch.zeros_like(video_latents)
-        mask = torch.zeros_like(video_latents[:, :1])
-        cond[:, :, idx] = video_latents[:, :, idx]
+        if self.controlnet.use_simplified_condition_embedding:       # :48-49 VAE latents
+            src = video_latents
+        else:                                                        # :50-52 pixels in [0, 1]
+            if video_data is None:
+                raise ValueError("the pixel-condition SparseCtrl needs the preprocessed frames (video_data)")
+            src = ((video_data.unsqueeze(0).to(video_latents.device, video_latents.dtype).permute(0, 2, 1, 3, 4) + 1) / 2)
+        cond = torch.zeros_like(src)
+        mask = torch.zeros_like(src[:, :1])
+        cond[:, :, idx] = src[:, :, idx]
         mask[:, :, idx] = 1
         down_res, mid_res = self.controlnet(noisy, step_t, encoder_hidden_states=uncond_embeddings, controlnet_cond=cond,
                                             conditioning_mask=mask, conditioning_scale=cfg.controlnet_scale,
@@ -166,7 +174,8 @@ def sample_video(self, eta: float = 0.0, generator=None, noisy_latents: Optional
     self.add_controlnet = add_controlnet
     cfg = self.input_config
     if add_controlnet and controlnet_images is not None:
-        self.controlnet_images = controlnet_images      # already VAE latents [1, 4, n_images, h, w] (:122-126)
+        # already what the ControlNet consumes (:122-128): VAE latents [1, 4, n, h, w], or pixels in [0, 1] [1, 3, n, H, W]
+        self.controlnet_images = controlnet_images
     elif add_controlnet:
         from PIL import Image
         import numpy as _np
@@ -175,8 +184,11 @@ def sample_video(self, eta: float = 0.0, generator=None, noisy_latents: Optional
             im = Image.open(path).convert("RGB").resize((cfg.width, cfg.height), Image.BILINEAR)
             imgs.append(torch.from_numpy(_np.array(im)).permute(2, 0, 1).float() / 255.0)
         px = torch.stack(imgs).to(dtype=self.vae.dtype, device=self.vae.device)
-        lat = self.vae.encode(px * 2.0 - 1.0).latent_dist.sample() * self.vae.config.scaling_factor
-        self.controlnet_images = lat.unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
+        if self.controlnet.use_simplified_condition_embedding:       # :122-126
+            lat = self.vae.encode(px * 2.0 - 1.0).latent_dist.sample() * self.vae.config.scaling_factor
+            self.controlnet_images = lat.unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
+        else:                                                        # :127-128 pixel-space condition as it is
+            self.controlnet_images = px.unsqueeze(0).permute(0, 2, 1, 3, 4).contiguous()
     device = self._execution_device
     if text_embeddings is None:
         text_embeddings = self._encode_prompt(cfg.new_prompt, device, 1, True, cfg.negative_prompt)

@@ -402,17 +402,33 @@ def unet_forward(sd, cfg, sample, timestep, text, guidance_block=1, only_motion_
 
 
 # ---- SparseCtrl (image-to-video conditioning encoder) ------------------------------------------------------
-def controlnet_param_shapes(cfg, conditioning_channels=4):
-    """Parameters of the reference SparseControlNetModel (sparse_controlnet.py:150-314) in the configuration of
-    configs/sparsectrl/latent_condition.yaml: simplified condition embedding (one 3x3 conv on latent + mask),
-    motion modules with a single Temporal_Self attention, 12 + 1 zero-initialised 1x1 output convs."""
+COND_EMBEDDING_CHANNELS = (16, 32, 96, 256)   # conditioning_embedding_out_channels default (sparse_controlnet.py:124)
+
+
+def controlnet_param_shapes(cfg, conditioning_channels=4, simplified=True, embedding_channels=COND_EMBEDDING_CHANNELS):
+    """Parameters of the reference SparseControlNetModel (sparse_controlnet.py:150-314): motion modules with a single
+    Temporal_Self attention, 12 + 1 zero-initialised 1x1 output convs, and the condition embedding of either
+    configs/sparsectrl/latent_condition.yaml (simplified: one 3x3 conv on VAE latent + mask, :181-184) or
+    configs/sparsectrl/image_condition.yaml (SparseControlNetConditioningEmbedding on pixels + mask, :49-82,185-190)."""
     ch = cfg["block_out_channels"]
     temb, xdim, L = ch[0] * 4, cfg["cross_attention_dim"], cfg["layers_per_block"]
     s = OrderedDict()
     s["conv_in.weight"] = (ch[0], cfg["in_channels"], 3, 3)
     s["conv_in.bias"] = (ch[0],)
-    s["controlnet_cond_embedding.weight"] = (ch[0], conditioning_channels + 1, 3, 3)
-    s["controlnet_cond_embedding.bias"] = (ch[0],)
+    if simplified:
+        s["controlnet_cond_embedding.weight"] = (ch[0], conditioning_channels + 1, 3, 3)
+        s["controlnet_cond_embedding.bias"] = (ch[0],)
+    else:
+        e = tuple(embedding_channels)
+        s["controlnet_cond_embedding.conv_in.weight"] = (e[0], conditioning_channels + 1, 3, 3)
+        s["controlnet_cond_embedding.conv_in.bias"] = (e[0],)
+        for i in range(len(e) - 1):
+            s["controlnet_cond_embedding.blocks.%d.weight" % (2 * i)] = (e[i], e[i], 3, 3)
+            s["controlnet_cond_embedding.blocks.%d.bias" % (2 * i)] = (e[i],)
+            s["controlnet_cond_embedding.blocks.%d.weight" % (2 * i + 1)] = (e[i + 1], e[i], 3, 3)
+            s["controlnet_cond_embedding.blocks.%d.bias" % (2 * i + 1)] = (e[i + 1],)
+        s["controlnet_cond_embedding.conv_out.weight"] = (ch[0], e[-1], 3, 3)
+        s["controlnet_cond_embedding.conv_out.bias"] = (ch[0],)
     s["time_embedding.linear_1.weight"] = (temb, ch[0])
     s["time_embedding.linear_1.bias"] = (temb,)
     s["time_embedding.linear_2.weight"] = (temb, temb)
@@ -448,11 +464,12 @@ def controlnet_param_shapes(cfg, conditioning_channels=4):
     return s
 
 
-def random_controlnet_state_dict(cfg, seed=4321, conditioning_channels=4):
+def random_controlnet_state_dict(cfg, seed=4321, conditioning_channels=4, simplified=True,
+                                 embedding_channels=COND_EMBEDDING_CHANNELS):
     """Seeded synthetic SparseCtrl weights; the zero-initialised layers (cond embedding, output convs, motion
     proj_out) get small random values instead, otherwise the encoder's output would be identically zero."""
     g = torch.Generator().manual_seed(seed)
-    shapes = controlnet_param_shapes(cfg, conditioning_channels)
+    shapes = controlnet_param_shapes(cfg, conditioning_channels, simplified, embedding_channels)
     sd = OrderedDict()
     for name, shape in shapes.items():
         if "norm" in name and len(shape) == 1:
@@ -489,16 +506,32 @@ def motion_module_single(sd, p, x, cfg):
     return tok.reshape(B, F, H, W, C).permute(0, 4, 1, 2, 3) + x
 
 
+def cond_embedding_pyramid(sd, x, p="controlnet_cond_embedding."):
+    """SparseControlNetConditioningEmbedding.forward (sparse_controlnet.py:72-82): conv_in, SiLU, then pairs of
+    (3x3 same-width, 3x3 stride-2 widening) convs each followed by SiLU, conv_out without activation.
+    x [B, channels + 1, F, 8H, 8W] in pixel space -> [B, C0, F, H, W]."""
+    h = Fn.silu(_conv(sd, p + "conv_in.", x))
+    i = 0
+    while (p + "blocks.%d.weight" % i) in sd:
+        h = Fn.silu(_conv(sd, p + "blocks.%d." % i, h, stride=2 if i % 2 else 1))
+        i += 1
+    return _conv(sd, p + "conv_out.", h)
+
+
 def controlnet_forward(sd, cfg, sample_shape, timestep, text, cond, mask, conditioning_scale=1.0):
-    """SparseControlNetModel.forward (sparse_controlnet.py:450-587) with set_noisy_sample_input_to_zero = True and
-    use_simplified_condition_embedding = True: returns (12 down residuals, mid residual), each scaled."""
+    """SparseControlNetModel.forward (sparse_controlnet.py:450-587) with set_noisy_sample_input_to_zero = True:
+    returns (12 down residuals, mid residual), each scaled.  The condition embedding is the simplified conv
+    (cond = VAE latents, latent resolution) or the pixel-space pyramid, whichever the state-dict holds."""
     B, _, F, H, W = sample_shape
     L = cfg["layers_per_block"]
     t = torch.as_tensor(timestep, device=text.device).reshape(-1).expand(B)
     temb = timestep_embedding(sd, t, cfg["block_out_channels"][0], text.dtype)
     x = sd["conv_in.bias"].reshape(1, -1, 1, 1, 1).expand(B, -1, F, H, W)                     # :516-518
-    emb = _conv({"weight": sd["controlnet_cond_embedding.weight"], "bias": sd["controlnet_cond_embedding.bias"]}, "",
-                torch.cat([cond, mask], dim=1))                                               # :522-525
+    if "controlnet_cond_embedding.weight" in sd:
+        emb = _conv({"weight": sd["controlnet_cond_embedding.weight"], "bias": sd["controlnet_cond_embedding.bias"]}, "",
+                    torch.cat([cond, mask], dim=1))                                           # :522-525
+    else:
+        emb = cond_embedding_pyramid(sd, torch.cat([cond, mask], dim=1))
     x = x + emb
     feats = [x]
     for i in range(4):

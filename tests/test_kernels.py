@@ -113,6 +113,24 @@ def test_gemm_split_k_plan(backend):
     assert L.mc_gemm_splitk_plan(131072, 320, 2880, 1) == 1      # plenty of tiles
     assert L.mc_gemm_splitk_plan(2048, 1280, 1280, 0) == 1       # K too shallow
     assert L.mc_gemm_splitk_plan(2048, 1000, 11520, 0) == 1      # N not a multiple of 320
+    # share hint (mode bits 8-9): with two launch sequences in flight a launch targets 128 CUs
+    assert L.mc_gemm_splitk_plan(8192, 1280, 11520, 1 | (1 << 8)) == 1              # 128 big tiles are enough now
+    assert L.mc_gemm_splitk_plan(2048, 1280, 11520, 1 | (1 << 8)) == (4 | (1 << 8))  # 32 big tiles x 4 ranges
+    assert L.mc_gemm_splitk_plan(1024, 1280, 23040, 1 | (1 << 8)) == (4 | (4 << 8))
+
+
+def test_gemm_share_hint_changes_the_choice_not_the_result(backend):
+    dev = backend
+    M, N, K = (512, 640, 256) if not big(dev) else (16384, 1280, 1280)
+    a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.05)
+    ref = a.float() @ w.float().t()
+    try:
+        for lanes in (1, 2, 4):
+            ops.set_gemm_share(lanes)
+            close(ops.gemm(a, w), ref, 2e-2, 5e-3, "share %d" % lanes)
+    finally:
+        ops.set_gemm_share(1)
+    assert ops._GEMM_SHARE == 0
 
 
 @pytest.mark.parametrize("M,N,K,tile", [(300, 136, 64, 128), (300, 136, 128, 128), (333, 200, 448, 128), (200, 72, 320, 64)])
