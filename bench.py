@@ -116,6 +116,20 @@ class GemmProbe:
         return groups
 
 
+def plan_rounds(nvideos, lanes):
+    """round sizes (videos in flight together) for `nvideos` videos on up to `lanes` lanes: full rounds first, and a
+    remainder of one is avoided by taking one video off the previous round (4 on 3 lanes -> [2, 2], 7 -> [3, 2, 2])"""
+    rounds = []
+    left = nvideos
+    while left > 0:
+        k = min(lanes, left)
+        if left - k == 1 and k > 2:
+            k -= 1
+        rounds.append(k)
+        left -= k
+    return rounds
+
+
 def synth_inputs(dev, F, H, W, seed):
     """latents = prepare_latents(seed) (pipeline_animation.py:316), text ~ N(0,1) [2,77,768],
     reference-video latents 0.18215 * N(0,1), extraction noise from the example seed."""
@@ -285,7 +299,7 @@ def reference_gpu_baseline(dev, size=512, sched=(30, 18, 0.4)):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=4, help="videos timed per GPU")
+    ap.add_argument("--steps", type=int, default=6, help="videos timed per GPU")
     ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up videos per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
@@ -297,10 +311,12 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
-    ap.add_argument("--inflight", type=int, default=2, help="independent videos processed concurrently per GPU (own HIP stream, "
-                    "own sampler / graphs each).  2 in flight: +8-10 %% videos/min at config 2 (kernel tails and the small "
-                    "16x16 / 8x8-level kernels of one video are filled by the other), results bit-identical to the one-at-a-time "
-                    "run (checked in the run: `eager.identical_to_graph_path`, tools/concurrency_check.py)")
+    ap.add_argument("--inflight", type=int, default=3, help="independent videos processed concurrently per GPU (own HIP stream, "
+                    "own sampler / graphs each).  At config 2: 2 in flight +8-10 %% videos/min over one (kernel tails and the "
+                    "small 16x16 / 8x8-level kernels of one video are filled by the others), 3 in flight another +2.6 %%, 4 lose; "
+                    "results bit-identical to the one-at-a-time run (checked in the run: `eager.identical_to_graph_path`, "
+                    "tools/concurrency_check.py).  --steps videos are processed in rounds of up to this many, never leaving "
+                    "a single video for the last round when it can be avoided (4 -> 2 + 2, 5 -> 3 + 2, 7 -> 3 + 2 + 2)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -388,8 +404,7 @@ def main():
             else:
                 step_events.append((i < G_STEPS, pending.pop(k), ev))
 
-        while done < nvideos:
-            k_act = min(NF, nvideos - done)
+        for k_act in plan_rounds(nvideos, NF):
             xs = sample_interleaved(smps[:k_act], lane_inputs[:k_act], streams[:k_act], add_noise_step=400, ctrl=ctrl,
                                     on_step=on_step)
             last = xs[0]
