@@ -309,6 +309,7 @@ def main():
     ap.add_argument("--guidance-scale", type=float, default=0.4)
     ap.add_argument("--sparsectrl", action="store_true", help="BASELINE config 4: add the SparseCtrl (i2v_rgb) encoder pass")
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
+    ap.add_argument("--gemm-lanes", type=int, default=0, help="value handed to ops.set_gemm_share (0 = the number of videos in flight)")
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     ap.add_argument("--inflight", type=int, default=3, help="independent videos processed concurrently per GPU (own HIP stream, "
@@ -376,7 +377,7 @@ def main():
     # fills (measured +8-10 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).  Results are
     # bit-identical to the one-at-a-time run since the library is built without packed-fp32 VALU code (csrc/temporal.hip).
     NF = max(1, min(args.inflight, args.steps))
-    ops.set_gemm_share(NF)      # every launch of this process, timed region and probe alike (tile / split-K choice only)
+    ops.set_gemm_share(args.gemm_lanes or NF)      # every launch of this process, timed region and probe alike (tile / split-K choice only)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     smps = [smp] + [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                                        num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE,
