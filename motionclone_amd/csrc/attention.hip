@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
                     for (int i = 0; i < 4; ++i)
                         if (kv0 + 16 * j + 4 * g + i > qrow) st[t][j][i] = -INFINITY;
             }
+            // ablation builds (tools/attn_ablate.py; never defined in the product build): -DMC_ATTN_NOMAX drops the running-max
+            // reduction, -DMC_ATTN_NOEXP the exponential, -DMC_ATTN_NOSOFTMAX everything between the two MFMA groups but the
+            // fp16 conversion - wrong results, they only price the softmax's VALU work against the MFMA work
             float mx = max3(st[t][0][0], st[t][0][1], st[t][0][2]);
             mx = max3(mx, st[t][0][3], st[t][1][0]);
             mx = max3(mx, st[t][1][1], st[t][1][2]);
@@ -277,14 +280,23 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
             mx = max3(mx, st[t][3][1], st[t][3][2]);
             mx = fmaxf(mx, st[t][3][3]);
             mx = grp_max(mx);
+#if defined(MC_ATTN_NOMAX) || defined(MC_ATTN_NOSOFTMAX)
+            mx = 0.f;
+#endif
             const float mnew = fmaxf(m[t], mx * sl2);   // sl2 > 0: max commutes with the scaling
             float rs = 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
+#if defined(MC_ATTN_NOSOFTMAX)
+                    float e0 = st[t][j][i], e1 = st[t][j][i + 1];
+#elif defined(MC_ATTN_NOEXP)
+                    float e0 = fmaf(st[t][j][i], sl2, -mnew), e1 = fmaf(st[t][j][i + 1], sl2, -mnew);
+#else
                     float e0 = fast_exp2(fmaf(st[t][j][i], sl2, -mnew));
                     float e1 = fast_exp2(fmaf(st[t][j][i + 1], sl2, -mnew));
+#endif
                     if (!ones_row) rs += e0 + e1;
                     half2_t h2 = pk_rtz(e0, e1);
                     pf[t][j >> 1][4 * (j & 1) + i] = h2[0];
