@@ -645,6 +645,14 @@ static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipSt
     static const int pf_env = getenv("MC_ATTN_PF") ? atoi(getenv("MC_ATTN_PF")) : -1;
     bool two = qt_env ? qt_env == 2 : P.Nq >= 256;
     bool pf = pf_env >= 0 ? pf_env != 0 : false;
+    if constexpr (DT == 3) {
+        // four query tiles per wave (a quarter of the K/V fragment reads per query, 253 registers, 2 waves per SIMD): the
+        // 4096-token level of a 512^2 video runs 1.72 -> 1.65 ms at B = 2 (tools/attn_ablate.py)
+        if (qt_env == 4 || (!qt_env && P.Nq >= 2048)) {
+            a_launch_fwd_cfg<DT, 4, false>(P, o, ldo, lse, s);
+            return;
+        }
+    }
     if (two) {
         if (pf) a_launch_fwd_cfg<DT, 2, true>(P, o, ldo, lse, s);
         else a_launch_fwd_cfg<DT, 2, false>(P, o, ldo, lse, s);

@@ -327,6 +327,20 @@ def test_self_attention_fwd_bwd(backend, d, Nq):
     close(_heads(dqkv[:, 2 * C:], nb, Nq, heads, d), gv, 1e-2, 2e-2, "attn dv")
 
 
+def test_self_attention_long_sequence_takes_four_query_tiles_per_wave(backend):
+    """Nq >= 2048 at d = 40 selects the 256-row workgroup (attention.hip a_launch_fwd); ragged tail on both axes"""
+    dev = backend
+    d, Nq, heads, nb = 40, 2048 + 37, (4 if big(dev) else 1), (2 if big(dev) else 1)
+    C = heads * d
+    qkv = rnd((nb * Nq, 3 * C), dev, 3, 0.7)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    o, lse = ops.attn_fwd(q, k, v, Nq, Nq, heads, d, nb)
+    Q, K, V = (_heads(t, nb, Nq, heads, d) for t in (q, k, v))
+    S = (Q @ K.transpose(-1, -2)) * d ** -0.5
+    close(_heads(o, nb, Nq, heads, d), S.softmax(-1) @ V, 1e-2, 1e-2, "attn fwd, 4 tiles per wave")
+    close(lse, torch.logsumexp(S, -1), 2e-3, 1e-3, "attn lse, 4 tiles per wave")
+
+
 def test_cross_attention_fwd_bwd(backend):
     dev = backend
     heads, d, B, F_, N, Nk = 2, 40, 2, 3, 50, 77

@@ -12,4 +12,8 @@ def timeit(fn, iters=10):
     for _ in range(iters): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / iters
-print(os.environ.get("MC_HIP_LIB", "default"), "attn_fwd level 0, B=2 (32 frames): %.3f ms" % timeit(lambda: ops.attn_fwd(q, k, v, N, N, 8, d, F)))
+o_ref = None
+print(os.environ.get("MC_HIP_LIB", "default"), "QT", os.environ.get("MC_ATTN_QT", "auto"), "attn_fwd level 0, B=2 (32 frames): %.3f ms" % timeit(lambda: ops.attn_fwd(q, k, v, N, N, 8, d, F)))
+o, lse = ops.attn_fwd(q, k, v, N, N, 8, d, F)
+ref = torch.nn.functional.scaled_dot_product_attention(*[t[:4 * N].view(4, N, 8, d).transpose(1, 2).float() for t in (q, k, v)])
+print("  max |o - sdpa| on 4 frames: %.3e" % (o[:4 * N].view(4, N, 8, d).transpose(1, 2).float() - ref).abs().max().item())
