@@ -525,8 +525,15 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             del eng, smp, smps
             torch.cuda.empty_cache()
-            res["reference_gpu_baseline"] = reference_gpu_baseline(dev) if (args.frames, args.size) == (16, 512) else None
-            res["cpu_baseline"] = cpu_baseline()
+            # the two baseline legs run after the measurement; a failure in one of them must not lose the bench line
+            try:
+                res["reference_gpu_baseline"] = reference_gpu_baseline(dev) if (args.frames, args.size) == (16, 512) else None
+            except Exception as e:   # noqa: BLE001
+                res["reference_gpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+            try:
+                res["cpu_baseline"] = cpu_baseline()
+            except Exception as e:   # noqa: BLE001
+                res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:
             res["cpu_baseline"] = None
         print(json.dumps(res))
