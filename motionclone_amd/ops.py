@@ -4,6 +4,8 @@ PyTorch is plumbing here: it owns device memory and the stream; every arithmetic
 into libmotionclone_hip.so.  Activations are fp16 token matrices [tokens, C] (token order
 (b, f, y, x)); a strided column window of a wider matrix is passed as a view (stride(1) == 1).
 """
+import threading
+
 import torch
 
 from . import lib
@@ -11,7 +13,12 @@ from . import lib
 DENSE, CONV_S1, CONV_S2, CONV_UP, TCONV_S2 = 0, 1, 2, 3, 4
 
 
-_STREAM = None   # HIP stream handle pinned for the duration of one engine call (see `scoped`)
+class _Pinned(threading.local):
+    stream = None   # HIP stream handle pinned for the duration of one engine call (see `scoped`); per host thread, like
+                    # torch's current stream, so engines driven from several threads keep their own streams
+
+
+_PIN = _Pinned()
 
 
 def scoped(fn):
@@ -19,22 +26,23 @@ def scoped(fn):
     launch (the lookup is ~1.8 us of the ~8 us a wrapper call costs on the host, and a step issues ~1000 launches).
     Evaluated when the method is entered, so a call made under hipGraph capture pins the capturing stream."""
     def wrapper(self, *a, **k):
-        global _STREAM
-        prev = _STREAM
+        pin = _PIN
+        prev = pin.stream
         dev = getattr(self, "dev", None)
         if prev is None and dev is not None and dev.type == "cuda":
-            _STREAM = torch.cuda.current_stream(dev).cuda_stream
+            pin.stream = torch.cuda.current_stream(dev).cuda_stream
         try:
             return fn(self, *a, **k)
         finally:
-            _STREAM = prev
+            pin.stream = prev
     wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
     return wrapper
 
 
 def _stream(t):
     if t.is_cuda:
-        return _STREAM if _STREAM is not None else torch.cuda.current_stream(t.device).cuda_stream
+        st = _PIN.stream
+        return st if st is not None else torch.cuda.current_stream(t.device).cuda_stream
     if not lib.is_emulated():
         raise RuntimeError("motionclone_amd kernels run on an MI355X; got a CPU tensor and no GPU library "
                            "(there is no CPU fallback)")
