@@ -27,6 +27,20 @@ REFERENCE_ROOT = os.environ.get("MC_REFERENCE_ROOT", "/root/reference")
 F, PX, STEPS, GUIDED, GSCALE = 4, 16, 3, 2, 0.3
 
 
+def px_of(kind):
+    """frame size in pixels: the tiny VAE of the t2v / i2v runs has 2 levels (16 px -> 8 x 8 latents); the sketch ControlNet's
+    condition pyramid always reduces by 8 (sparse_controlnet.py:124), so that run uses a 4-level VAE and 64 px frames"""
+    return 64 if kind == "i2v_sketch" else PX
+
+
+def vae_config_of(kind):
+    from oracle import vae_ref as V
+    cfg = dict(V.TINY_VAE_CONFIG)
+    if kind == "i2v_sketch":
+        cfg["block_out_channels"] = (64, 64, 64, 64)
+    return cfg
+
+
 # ---- stand-ins -------------------------------------------------------------------------------------------------------
 class DictConfig(dict):
     """attribute-style dict (the slice of omegaconf.DictConfig the scripts use: attribute get / set, .get)"""
@@ -178,11 +192,12 @@ def write_assets(work, kind, n_examples=1):
     torch.save({k: v for k, v in sd.items() if "motion_modules." not in k},
                os.path.join(root, "unet", "diffusion_pytorch_model.bin"))
     torch.save({"state_dict": {k: v for k, v in sd.items() if "motion_modules." in k}}, os.path.join(work, "mm.ckpt"))
-    vcfg = dict(V.TINY_VAE_CONFIG)
+    vcfg = vae_config_of(kind)
+    px = px_of(kind)
     vsd = {k: v.half().float() for k, v in V.random_state_dict(vcfg, seed=77).items()}
     json.dump(dict(in_channels=3, out_channels=3, latent_channels=4, block_out_channels=list(vcfg["block_out_channels"]),
                    layers_per_block=vcfg["layers_per_block"], norm_num_groups=vcfg["norm_num_groups"],
-                   scaling_factor=0.18215, sample_size=PX, act_fn="silu", _class_name="AutoencoderKL"),
+                   scaling_factor=0.18215, sample_size=px, act_fn="silu", _class_name="AutoencoderKL"),
               open(os.path.join(root, "vae", "config.json"), "w"))
     torch.save(vsd, os.path.join(root, "vae", "diffusion_pytorch_model.bin"))
     ccfg = tiny_clip_config()
@@ -216,19 +231,22 @@ def write_assets(work, kind, n_examples=1):
     rng = np.random.RandomState(3)
     np.save(os.path.join(work, "clip.mp4.npy"), rng.randint(0, 256, size=(9, 20, 24, 3)).astype(np.uint8))
     example = dict(video_path=os.path.join(work, "clip.mp4"), new_prompt="a cat runs", seed=42)
-    if kind == "i2v":
+    if kind in ("i2v", "i2v_sketch"):
         from PIL import Image
         mk1 = dict(mk, attention_block_types=["Temporal_Self"])
+        simplified = kind == "i2v"     # configs/sparsectrl/latent_condition.yaml vs image_condition.yaml
         yaml.safe_dump(dict(controlnet_additional_kwargs=dict(
-            set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=True, conditioning_channels=4,
+            set_noisy_sample_input_to_zero=True, use_simplified_condition_embedding=simplified,
+            conditioning_channels=4 if simplified else 3,
             use_motion_module=True, motion_module_resolutions=[1, 2, 4, 8], motion_module_mid_block=False,
             motion_module_type="Vanilla", motion_module_kwargs=mk1)), open(os.path.join(work, "cn_config.yaml"), "w"))
-        cnsd = {k: v.half().float() for k, v in U.random_controlnet_state_dict(cfg).items()}
+        cnsd = {k: v.half().float() for k, v in U.random_controlnet_state_dict(
+            cfg, conditioning_channels=4 if simplified else 3, simplified=simplified).items()}
         torch.save({"controlnet": cnsd}, os.path.join(work, "v3_sd15_sparsectrl_rgb.ckpt"))
         infer.update(controlnet_path=os.path.join(work, "v3_sd15_sparsectrl_rgb.ckpt"),
                      controlnet_config=os.path.join(work, "cn_config.yaml"), adapter_lora_path="", guidance_steps=GUIDED)
         img = os.path.join(work, "cond0.png")
-        Image.fromarray(rng.randint(0, 256, size=(PX, PX, 3)).astype(np.uint8)).save(img)
+        Image.fromarray(rng.randint(0, 256, size=(px, px, 3)).astype(np.uint8)).save(img)
         example.update(condition_image_paths=[img], image_index=[0], controlnet_scale=0.8)
     yaml.safe_dump(infer, open(os.path.join(work, "infer.yaml"), "w"))
     with open(os.path.join(work, "examples.jsonl"), "w") as f:
@@ -291,6 +309,7 @@ def main():
     rec = {}
     install_recorders(rec)
     script = os.path.join(REFERENCE_ROOT, "t2v_video_sample.py" if kind == "t2v" else "i2v_video_sample.py")
+    px = px_of(kind)
     common = dict(pretrained_model_path=os.path.join(work, "sd"), inference_config=os.path.join(work, "infer.yaml"),
                   examples=os.path.join(work, "examples.jsonl"))
     if launch:
@@ -307,7 +326,7 @@ def main():
     assert os.path.abspath(mu.__file__).startswith(ROOT), mu.__file__
     args = argparse.Namespace(motion_representation_save_dir=os.path.join(work, "motion_representation"),
                               generated_videos_save_dir=os.path.join(work, "generated_videos"), visible_gpu=None,
-                              default_seed=2025, L=F, W=PX, H=PX, without_xformers=False, **common)
+                              default_seed=2025, L=F, W=px, H=px, without_xformers=False, **common)
     ns["main"](args)
     rec["videos"] = written
     torch.save(rec, os.path.join(work, "record.pt"))

@@ -32,8 +32,8 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
-N_EXAMPLES = {"t2v": 2, "i2v": 1}
-LAST = {"t2v": ("a dog walks 1", 2027), "i2v": ("a cat runs", 42)}
+N_EXAMPLES = {"t2v": 2, "i2v": 1, "i2v_sketch": 1}
+LAST = {"t2v": ("a dog walks 1", 2027), "i2v": ("a cat runs", 42), "i2v_sketch": ("a cat runs", 42)}
 
 
 def run_harness(kind, work):
@@ -56,7 +56,7 @@ def runs(tmp_path_factory):
     return get
 
 
-@pytest.mark.parametrize("kind", ["t2v", "i2v"])
+@pytest.mark.parametrize("kind", ["t2v", "i2v", "i2v_sketch"])
 def test_unmodified_entry_script_matches_oracle(kind, runs):
     import entry_harness as EH
     tmp_path, rec = runs(kind)
@@ -78,9 +78,16 @@ def test_unmodified_entry_script_matches_oracle(kind, runs):
     assert ex["t"] == 400 and ex["noisy"].shape == (1, 4, EH.F, 8, 8)
     res = None
     csd = None
-    if kind == "i2v":
-        csd = {k: v.half().float() for k, v in U.random_controlnet_state_dict(cfg).items()}
+    i2v = kind != "t2v"
+    if i2v:
+        simplified = kind == "i2v"
+        csd = {k: v.half().float() for k, v in U.random_controlnet_state_dict(
+            cfg, conditioning_channels=4 if simplified else 3, simplified=simplified).items()}
         c0 = rec["controlnet_calls"][0]
+        # latent_condition.yaml: the condition is the VAE latent of the frame; image_condition.yaml: the frame itself in [0, 1]
+        assert tuple(c0["cond"].shape) == ((1, 4, EH.F, 8, 8) if simplified else (1, 3, EH.F, EH.px_of(kind), EH.px_of(kind)))
+        if not simplified:
+            assert 0.0 <= float(c0["cond"].min()) and float(c0["cond"].max()) <= 1.0 and float(c0["cond"][:, :, 0].max()) > 0.5
         assert c0["t"] == 400 and c0["B"] == 1 and abs(c0["scale"] - 0.8) < 1e-6
         assert float(c0["mask"][:, :, 0].min()) == 1.0 and float(c0["mask"][:, :, 1:].abs().max()) == 0.0
         with torch.no_grad():
@@ -109,10 +116,10 @@ def test_unmodified_entry_script_matches_oracle(kind, runs):
     hp = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10, guidance_steps=Gs)
     rep_cpu = {k: [a.float(), b] for k, (a, b) in pt.items()}
     x, text = lp["lat0"].float(), lp["text"].float()
-    assert (kind == "i2v") == (lp["ctrl"] is not None)
+    assert i2v == (lp["ctrl"] is not None)
     for s in range(N):
         d = m = None
-        if kind == "i2v":
+        if i2v:
             with torch.no_grad():
                 d, m = U.controlnet_forward(csd, cfg, (2, 4, EH.F, 8, 8), int(ts[s]), text, lp["ctrl"]["cond"].float(),
                                             lp["ctrl"]["mask"].float(), 0.8)
@@ -126,8 +133,8 @@ def test_unmodified_entry_script_matches_oracle(kind, runs):
 
     # ---- decoded video handed to imageio.mimwrite --------------------------------------------------------------------
     frames = np.load(rec["videos"][-1] + ".npy")    # the records are those of the last example
-    assert frames.dtype == np.uint8 and frames.shape == (EH.F, EH.PX, EH.PX, 3)
-    vcfg = dict(V.TINY_VAE_CONFIG)
+    assert frames.dtype == np.uint8 and frames.shape == (EH.F, EH.px_of(kind), EH.px_of(kind), 3)
+    vcfg = EH.vae_config_of(kind)
     vsd = {k: v.half().float() for k, v in V.random_state_dict(vcfg, seed=77).items()}
     with torch.no_grad():
         want = V.decode_latents(vsd, vcfg, lp["last"].float())[0].permute(1, 2, 3, 0).numpy()   # f h w c in [0, 1]
