@@ -36,24 +36,34 @@ N_EXAMPLES = {"t2v": 2, "i2v": 1, "i2v_sketch": 1}
 LAST = {"t2v": ("a dog walks 1", 2027), "i2v": ("a cat runs", 42), "i2v_sketch": ("a cat runs", 42)}
 
 
-def run_harness(kind, work):
+def start_harness(kind, work):
     env = dict(os.environ, PYTHONPATH=ROOT)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), kind, str(work), "--examples",
-                        str(N_EXAMPLES[kind])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=str(work))
-    assert r.returncode == 0 and "ENTRY_OK" in r.stdout, r.stdout[-4000:]
-    return torch.load(os.path.join(str(work), "record.pt"))
+    return subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), kind, str(work), "--examples",
+                             str(N_EXAMPLES[kind])], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env,
+                            cwd=str(work))
 
 
 @pytest.fixture(scope="module")
 def runs(tmp_path_factory):
-    cache = {}
+    """every kind's child process is started on first use, so the three script runs overlap (each takes about a minute on
+    the host simulator)"""
+    procs, cache = {}, {}
 
     def get(kind):
+        if not procs:
+            for k in N_EXAMPLES:
+                work = tmp_path_factory.mktemp(k)
+                procs[k] = (work, start_harness(k, work))
         if kind not in cache:
-            work = tmp_path_factory.mktemp(kind)
-            cache[kind] = (work, run_harness(kind, work))
+            work, p = procs[kind]
+            out = p.communicate(timeout=1500)[0]
+            assert p.returncode == 0 and "ENTRY_OK" in out, out[-4000:]
+            cache[kind] = (work, torch.load(os.path.join(str(work), "record.pt")))
         return cache[kind]
-    return get
+    yield get
+    for k, (_, p) in procs.items():
+        if p.poll() is None:
+            p.kill()
 
 
 @pytest.mark.parametrize("kind", ["t2v", "i2v", "i2v_sketch"])
