@@ -679,26 +679,35 @@ static void a_launch_dkdv_cfg(const AParams& P, const half_t* dO, int lddo, cons
     allow_big_smem(attn_bwd_dkdv_kernel<DT, KT>, smem);
     MC_LAUNCH((attn_bwd_dkdv_kernel<DT, KT>), grid, dim3(256), smem, s, P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv);
 }
-// two row tiles per wave once there are enough rows to fill the chip with the larger blocks (MC_ATTN_BQT overrides);
+// two row tiles per wave once there are enough rows to fill the chip with the larger blocks, four for the 4096-token level
+// at d = 40 (level-0 backward of a 512^2 video 2.86 -> 2.55 ms, tools/attn_ablate.py; MC_ATTN_BQT overrides);
 // head dim 160 keeps one tile (the accumulators alone would need > 256 registers)
 static int bwd_tiles(int rows, int dt) {
     static const int env = getenv("MC_ATTN_BQT") ? atoi(getenv("MC_ATTN_BQT")) : 0;
     if (dt > 5) return 1;
-    return env ? env : (rows >= 512 ? 2 : 1);
+    if (env) return env;
+    if (dt == 3 && rows >= 2048) return 4;
+    return rows >= 512 ? 2 : 1;
 }
 template <int DT>
 static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse,
                         float* Dbuf, half_t* dq, int lddq, hipStream_t s) {
+    if constexpr (DT == 3) {   // four row tiles per wave
+        if (bwd_tiles(P.Nq, DT) == 4) return a_launch_dq_cfg<DT, 4>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
+    }
     if constexpr (DT <= 5) {
-        if (bwd_tiles(P.Nq, DT) == 2) return a_launch_dq_cfg<DT, 2>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
+        if (bwd_tiles(P.Nq, DT) >= 2) return a_launch_dq_cfg<DT, 2>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
     }
     a_launch_dq_cfg<DT, 1>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
 }
 template <int DT>
 static void a_launch_dkdv(const AParams& P, const half_t* dO, int lddo, const float* lse, const float* Dbuf,
                           half_t* dk, int lddk, half_t* dv, int lddv, hipStream_t s) {
+    if constexpr (DT == 3) {
+        if (bwd_tiles(P.Nk, DT) == 4) return a_launch_dkdv_cfg<DT, 4>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
+    }
     if constexpr (DT <= 5) {
-        if (bwd_tiles(P.Nk, DT) == 2) return a_launch_dkdv_cfg<DT, 2>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
+        if (bwd_tiles(P.Nk, DT) >= 2) return a_launch_dkdv_cfg<DT, 2>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
     }
     a_launch_dkdv_cfg<DT, 1>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
 }

@@ -339,6 +339,16 @@ def test_self_attention_long_sequence_takes_four_query_tiles_per_wave(backend):
     S = (Q @ K.transpose(-1, -2)) * d ** -0.5
     close(_heads(o, nb, Nq, heads, d), S.softmax(-1) @ V, 1e-2, 1e-2, "attn fwd, 4 tiles per wave")
     close(lse, torch.logsumexp(S, -1), 2e-3, 1e-3, "attn lse, 4 tiles per wave")
+    # the backward takes four row tiles per wave at this length too (attention.hip bwd_tiles)
+    Q, K, V = (t.detach().requires_grad_() for t in (Q, K, V))
+    ref = ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ V
+    do = rnd((nb * Nq, C), dev, 4)
+    gq, gk, gv = torch.autograd.grad(ref, (Q, K, V), _heads(do, nb, Nq, heads, d))
+    dqkv = torch.zeros_like(qkv)
+    ops.attn_bwd(q, k, v, o, do, lse, Nq, Nq, heads, d, nb, dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+    close(_heads(dqkv[:, :C], nb, Nq, heads, d), gq, 1e-2, 2e-2, "attn dq, 4 tiles per wave")
+    close(_heads(dqkv[:, C:2 * C], nb, Nq, heads, d), gk, 1e-2, 2e-2, "attn dk, 4 tiles per wave")
+    close(_heads(dqkv[:, 2 * C:], nb, Nq, heads, d), gv, 1e-2, 2e-2, "attn dv, 4 tiles per wave")
 
 
 def test_cross_attention_fwd_bwd(backend):

@@ -17,3 +17,14 @@ print(os.environ.get("MC_HIP_LIB", "default"), "QT", os.environ.get("MC_ATTN_QT"
 o, lse = ops.attn_fwd(q, k, v, N, N, 8, d, F)
 ref = torch.nn.functional.scaled_dot_product_attention(*[t[:4 * N].view(4, N, 8, d).transpose(1, 2).float() for t in (q, k, v)])
 print("  max |o - sdpa| on 4 frames: %.3e" % (o[:4 * N].view(4, N, 8, d).transpose(1, 2).float() - ref).abs().max().item())
+do = (torch.randn(F * N, 8 * d, device=dev) * 0.5).half()
+F1 = 16   # the taped half runs at B = 1
+dqkv = torch.zeros(F1 * N, 3 * 8 * d, device=dev, dtype=torch.float16)
+C = 8 * d
+def bwd():
+    ops.attn_bwd(q[:F1 * N], k[:F1 * N], v[:F1 * N], o[:F1 * N], do[:F1 * N], lse[:F1], N, N, 8, d, F1,
+                 dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+try:
+    print("  BQT", os.environ.get("MC_ATTN_BQT", "auto"), "attn_bwd level 0, B=1 (16 frames): %.3f ms" % timeit(bwd, 5), " checksum %.6f" % dqkv.float().abs().mean().item())
+except Exception as e:
+    print("  bwd failed:", e)
