@@ -99,7 +99,11 @@ struct Epilogue {
                     half8_t o;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) o[e] = to_half(v[e]);
-                    if (!(p.dbg & 1)) st8(crow + (size_t)it * RPP * p.ldc, o);
+                    if (p.dbg & 32) {   // experiment (MC_GEMM_DEBUG=32): streaming (nt) stores for the output tile
+#ifndef MC_EMU
+                        __builtin_nontemporal_store(o, reinterpret_cast<half8_t*>(crow + (size_t)it * RPP * p.ldc));
+#endif
+                    } else if (!(p.dbg & 1)) st8(crow + (size_t)it * RPP * p.ldc, o);
                 }
             }
             return;
