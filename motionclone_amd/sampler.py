@@ -104,7 +104,7 @@ class MotionCloneSampler:
         guided = i < self.G
         rsig = tuple((k, tuple(v[0].shape)) for k, v in rep_dev.items()) if guided else ()
         csig = None if ctrl is None else (tuple(ctrl["cond"].shape), float(ctrl.get("scale", 1.0)))
-        key = (i, tuple(latents.shape), tuple(text.shape), rsig, csig)
+        key = (i, tuple(latents.shape), tuple(text.shape), rsig, csig, ops._GEMM_SHARE)   # the GEMM geometry is baked in
         ent = self._graphs.get(key)
         if ent is None:
             s_lat, s_text = latents.clone(), text.clone()
@@ -198,6 +198,8 @@ def sample_interleaved(samplers, jobs, streams, add_noise_step=400, ctrl=None, o
     targets half of the CUs per launch, +3.6 % videos/min).  `on_step(k, i, enter)` is called around every
     step inside the lane's stream context (bench.py records its events there).  Returns the final latents per job."""
     n = len(jobs)
+    if n == 0:
+        return []
     if n > len(samplers) or n > len(streams):
         raise ValueError("sample_interleaved: %d jobs for %d samplers / %d streams" % (n, len(samplers), len(streams)))
     cur = torch.cuda.current_stream(jobs[0][0].device)
