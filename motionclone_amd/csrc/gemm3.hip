@@ -58,7 +58,20 @@ __global__ __launch_bounds__(64 * NWM * NWN, WPE) void gemm3_kernel(GemmParams p
     const int pid = blockIdx.x;
     const int xcd = pid & 7, local = pid >> 3;
     const int tn = local % tilesN;
-    const int tm = (local / tilesN) * 8 + xcd;
+    // Linear layers: the N-tiles of one M-tile sit on one XCD (consecutive slots) and share the activation tile in its L2.
+    // Convolutions: every XCD owns a CONTIGUOUS range of M-tiles instead, so that vertically adjacent tiles - which
+    // read each other's halo image rows through the shifted taps - run on the same XCD at about the same time and
+    // meet in its L2 (256-row tiles = 4 image rows at 64 px: 6 rows are read per tile, 1.5x if the halo is private).
+    // Measured (tools/conv_bench.py, tools/pmc_ab.sh): the level-0 conv (one N-tile) 282 -> 269 us and 239 -> 200 MB of HBM
+    // traffic per launch (1.41x -> 1.18x algorithmic); with two or more N-tiles the same order was 3 % slower, so those keep
+    // the Linear order.
+    int tm;
+    if (MODE == DENSE || tilesN > 1) {
+        tm = (local / tilesN) * 8 + xcd;
+    } else {
+        const int per = (tilesM + 7) >> 3;
+        tm = (local / tilesN) < per ? xcd * per + local / tilesN : tilesM;
+    }
     if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
 
