@@ -187,7 +187,7 @@ class MotionCloneSampler:
         return latents
 
 
-def sample_interleaved(samplers, jobs, streams, add_noise_step=400, ctrl=None, on_step=None):
+def sample_interleaved(samplers, jobs, streams=None, add_noise_step=400, ctrl=None, on_step=None):
     """Several independent videos in flight on one GPU (examples are the unit of parallelism).
 
     `jobs[k] = (latents, text [2,77,768], reference_video_latents, extraction_noise)` runs on `samplers[k]` / `streams[k]`
@@ -196,29 +196,35 @@ def sample_interleaved(samplers, jobs, streams, add_noise_step=400, ctrl=None, o
     to running the jobs one after the other (tools/concurrency_check.py) under the same `ops.set_gemm_share` setting
     (callers that keep 2 lanes busy set it to 2 once, before any graph is captured: the GEMM tile / split-K choice then
     targets half of the CUs per launch, +3.6 % videos/min).  `on_step(k, i, enter)` is called around every
-    step inside the lane's stream context (bench.py records its events there).  Returns the final latents per job."""
+    step inside the lane's stream context (bench.py records its events there).  `streams=None` issues everything on the
+    current stream (same issue order, no overlap; what the host-simulator tests use).  Returns the final latents per job."""
     n = len(jobs)
     if n == 0:
         return []
-    if n > len(samplers) or n > len(streams):
-        raise ValueError("sample_interleaved: %d jobs for %d samplers / %d streams" % (n, len(samplers), len(streams)))
-    cur = torch.cuda.current_stream(jobs[0][0].device)
-    for st in streams[:n]:
-        st.wait_stream(cur)
+    if n > len(samplers) or (streams is not None and n > len(streams)):
+        raise ValueError("sample_interleaved: %d jobs for %d samplers / %s streams" % (
+            n, len(samplers), "no" if streams is None else len(streams)))
+    import contextlib
+    lane = (lambda k: contextlib.nullcontext()) if streams is None else (lambda k: torch.cuda.stream(streams[k]))
+    if streams is not None:
+        cur = torch.cuda.current_stream(jobs[0][0].device)
+        for st in streams[:n]:
+            st.wait_stream(cur)
     xs, reps = [None] * n, [None] * n
     for k, (lat, text, vid, noise) in enumerate(jobs):
-        with torch.cuda.stream(streams[k]):
+        with lane(k):
             rep = samplers[k].extract(vid, noise, text[0:1], add_noise_step=add_noise_step, ctrl=ctrl)
             reps[k] = samplers[k].engine.prepare_representation(rep)
             xs[k] = lat
     for i in range(len(samplers[0].timesteps)):
         for k in range(n):
-            with torch.cuda.stream(streams[k]):
+            with lane(k):
                 if on_step is not None:
                     on_step(k, i, True)
                 xs[k] = samplers[k].step(xs[k], i, jobs[k][1], reps[k], ctrl=ctrl)
                 if on_step is not None:
                     on_step(k, i, False)
-    for st in streams[:n]:
-        cur.wait_stream(st)
+    if streams is not None:
+        for st in streams[:n]:
+            cur.wait_stream(st)
     return xs
