@@ -116,15 +116,22 @@ def obtain_motion_representation(self, generator=None, motion_representation_pat
 
 
 def get_temp_attn_prob(self, index_select=None):
-    """:260-283: P = softmax(scale q k^T) [(b n), heads, F, F] for every hooked temporal attention."""
-    if index_select is not None:
-        raise NotImplementedError("index_select is never passed on the reference path")
+    """:260-283: P = softmax(scale q k^T) [(b n), heads, F, F] for every hooked temporal attention.  `index_select`
+    (a 0/1 flag per equal block of the (b n) axis, :267-271 - e.g. [0, 1] keeps the second batch element) picks rows of
+    the result: the probabilities are computed per (b, pixel) anyway, the selection is data movement."""
     out = {}
     for name, module in self.unet.named_modules():
         if "VersatileAttention" in type(module).__name__ and classify_blocks(self.input_config.motion_guidance_blocks, name):
             r = module.processor.key
             C, g = r["C"], r["geo"]
-            out[name] = ops.tattn_prob(r["qkv"][:, :C], r["qkv"][:, C:2 * C], g.B, g.F, g.hw, module.heads, r["d"])
+            prob = ops.tattn_prob(r["qkv"][:, :C], r["qkv"][:, C:2 * C], g.B, g.F, g.hw, module.heads, r["d"])
+            if index_select is not None:
+                rows = prob.shape[0]
+                if rows % len(index_select):
+                    raise ValueError("index_select of length %d does not divide %d rows" % (len(index_select), rows))
+                keep = torch.repeat_interleave(torch.tensor(index_select), repeats=rows // len(index_select)).bool()
+                prob = prob[keep.to(prob.device)]
+            out[name] = prob
     return out
 
 

@@ -75,6 +75,12 @@ def test_entry_script_flow_matches_oracle(backend):
     assert (v.cpu() - rep[hooked[0]][0].float().cpu()).abs().max() < 2e-3
     loss = pipe.compute_temp_loss(prob)
     assert loss.item() < 1e-5  # same latents, same representation -> zero guidance loss
+    # index_select (:267-271): 0/1 flags over equal blocks of the (b n) axis
+    half = pipe.get_temp_attn_prob(index_select=[0, 1])
+    assert all(torch.equal(half[k], prob[k][prob[k].shape[0] // 2:]) for k in prob)
+    quarter = pipe.get_temp_attn_prob(index_select=[1, 0, 0, 1])
+    n4 = prob[hooked[0]].shape[0] // 4
+    assert torch.equal(quarter[hooked[0]], torch.cat([prob[hooked[0]][:n4], prob[hooked[0]][3 * n4:]]))
 
     lat0 = torch.randn(1, 4, 4, 8, 8, generator=torch.Generator().manual_seed(2025)).half()
     out = pipe.sample_video(generator=None, noisy_latents=lat0.to(dev), text_embeddings=text.to(dev), decode=False)
