@@ -446,8 +446,10 @@ def ddim_step_general(sample, model_output, score, noise, coef, want_prev=True, 
     return prev, x0, eps
 
 
-def cfg_ddim_step(eps_c, eps_u, x, score, cfg, a_t, a_prev, score_coef, want_eps=False):
-    """x, score: [1, CL, F, H, W]; eps_*: channels-last token matrices (first CL columns)."""
+def cfg_ddim_step(eps_c, eps_u, x, score, cfg, a_t, a_prev, score_coef, want_eps=False, sigma=0.0):
+    """x, score: [1, CL, F, H, W]; eps_*: channels-last token matrices (first CL columns).  sigma = eta * sqrt(variance)
+    of schedule_customized_step (:364-365): the direction coefficient becomes sqrt(1 - a_prev - sigma^2) (:386); the
+    caller adds sigma * noise (:391-405)."""
     B, CL, F, H, W = x.shape
     if B != 1 or (score is not None and tuple(score.shape) != tuple(x.shape)):
         raise ValueError("cfg_ddim_step updates one video per call: x %s, score %s" % (tuple(x.shape), None if score is None else tuple(score.shape)))
@@ -459,5 +461,5 @@ def cfg_ddim_step(eps_c, eps_u, x, score, cfg, a_t, a_prev, score_coef, want_eps
     assert _ld(eps_c) == _ld(eps_u)
     lib.call("mc_cfg_ddim_step_f16", _p(eps_c), _p(eps_u), _ld(eps_c), _p(x), _p(score), _p(out), _p(eps_out),
              float(cfg), float(a_t) ** 0.5, float(1.0 - a_t) ** 0.5, float(a_prev) ** 0.5,
-             float(1.0 - a_prev) ** 0.5, float(score_coef), CL, F, H * W, _stream(x))
+             max(float(1.0 - a_prev) - float(sigma) ** 2, 0.0) ** 0.5, float(score_coef), CL, F, H * W, _stream(x))
     return (out, eps_out) if want_eps else out

@@ -137,15 +137,30 @@ class MotionCloneSampler:
         graph.replay()
         return s_out
 
-    def step(self, latents, i, text, rep_dev, aux=None, ctrl=None):
+    def step(self, latents, i, text, rep_dev, aux=None, ctrl=None, eta=0.0, generator=None, variance_noise=None):
         """single_step_video (motionclone_functions.py:173-257): text = [uncond, cond] embeddings [2, n, dim];
-        ctrl = dict(cond, mask, scale) enables the SparseCtrl pass of :176-197 (one B=2 encoder run per step)"""
+        ctrl = dict(cond, mask, scale) enables the SparseCtrl pass of :176-197 (one B=2 encoder run per step);
+        eta / generator / variance_noise = the `extra_step_kwargs` handed on to schedule_customized_step (:241,255):
+        eta > 0 adds eta * sigma_t * noise, drawn like randn_tensor unless given (never captured in a graph)"""
+        if eta:
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"
+                                 " `variance_noise` stays `None`.")
+            t, a_t, a_prev = self._alphas(i)
+            sigma = float(eta) * max((1.0 - a_prev) / (1.0 - a_t) * (1.0 - a_t / a_prev), 0.0) ** 0.5
+            prev = self._step_eager(latents, i, text, rep_dev, aux, ctrl, sigma)
+            if variance_noise is None:
+                gdev = generator.device if generator is not None else latents.device
+                variance_noise = torch.randn(latents.shape, generator=generator, device=gdev, dtype=latents.dtype).to(latents.device)
+            flat = prev.reshape(-1, 8)
+            ops.add(flat, variance_noise.to(prev.dtype).contiguous().reshape(flat.shape), out=flat, sa=1.0, sb=sigma)
+            return prev
         if self._graphs is not None and aux is None and latents.is_cuda:
             return self._graphed_step(latents, i, text, rep_dev, ctrl)
         return self._step_eager(latents, i, text, rep_dev, aux, ctrl)
 
     @ops.scoped
-    def _step_eager(self, latents, i, text, rep_dev, aux=None, ctrl=None):
+    def _step_eager(self, latents, i, text, rep_dev, aux=None, ctrl=None, sigma=0.0):
         from .engine import split_residuals
         eng = self.engine
         t, a_t, a_prev = self._alphas(i)
@@ -171,12 +186,12 @@ class MotionCloneSampler:
             if aux is not None:
                 aux.update(eps_u=eps_u, eps_c=eps_c, grad=grad, loss=loss)
             coef = self.score_gs * (1.0 - a_t) ** 0.5
-            return ops.cfg_ddim_step(eps_c, eps_u, latents, grad, self.cfg_scale, a_t, a_prev, coef)
+            return ops.cfg_ddim_step(eps_c, eps_u, latents, grad, self.cfg_scale, a_t, a_prev, coef, sigma=sigma)
         eps2 = eng.forward(latents.expand(2, -1, -1, -1, -1), t, text, down_residuals=down, mid_residual=mid)
         T1 = eps2.shape[0] // 2
         if aux is not None:
             aux.update(eps_u=eps2[:T1], eps_c=eps2[T1:])
-        return ops.cfg_ddim_step(eps2[T1:], eps2[:T1], latents, None, self.cfg_scale, a_t, a_prev, 0.0)
+        return ops.cfg_ddim_step(eps2[T1:], eps2[:T1], latents, None, self.cfg_scale, a_t, a_prev, 0.0, sigma=sigma)
 
     def sample(self, latents, text, rep, progress=None, ctrl=None):
         rep_dev = self.engine.prepare_representation(rep)

@@ -171,7 +171,9 @@ def single_step_video(self, noisy_latents, step_index, step_t, extra_step_kwargs
     if getattr(self, "_mc_rep_src", None) is not self.motion_representation_dict:
         self._mc_rep_dev = smp.engine.prepare_representation(self.motion_representation_dict)
         self._mc_rep_src = self.motion_representation_dict
-    out = smp.step(noisy_latents.half(), step_index, self.text_embeddings.half(), self._mc_rep_dev, ctrl=ctrl)
+    kw = dict(extra_step_kwargs or {})      # prepare_extra_step_kwargs: eta / generator, handed to customized_step (:241,255)
+    out = smp.step(noisy_latents.half(), step_index, self.text_embeddings.half(), self._mc_rep_dev, ctrl=ctrl,
+                   eta=float(kw.get("eta", 0.0) or 0.0), generator=kw.get("generator") if kw.get("eta") else None)
     return out.detach()
 
 

@@ -200,3 +200,35 @@ def test_interleaved_sampling_equals_one_at_a_time(backend, tiny):
         finally:
             ops.set_gemm_share(1)
         assert all(rel_err(a, b) < 5e-3 for a, b in zip(shared, seq))
+
+
+def test_step_with_eta_matches_the_scheduler_formula(backend, tiny):
+    """extra_step_kwargs of single_step_video (motionclone_functions.py:241,255): eta > 0 changes the direction coefficient
+    to sqrt(1 - a_prev - sigma^2) and adds sigma * noise (:364-365,386,391-405); a guided and a plain step"""
+    dev = backend
+    cfg, sd = tiny
+    eng = UNet3DEngine(sd, cfg, dev)
+    lat, text, vid, noise = [t.half().to(dev) for t in make_inputs(cfg, F=2)]
+    N, Gs, gscale = 4, 2, 0.3        # step Gs is a plain step that is not the last one (the last has sigma = 0)
+    smp = MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gscale, **HP)
+    rep_dev = eng.prepare_representation(smp.extract(vid, noise, text[0:1]))
+    ts = G.uneven_timesteps(N, Gs, gscale)
+    B, _, F, H, W = lat.shape
+    z = torch.randn(lat.shape, generator=torch.Generator().manual_seed(21)).half()
+    for i in (0, Gs):
+        aux = {}
+        plain0 = smp.step(lat, i, text, rep_dev, aux=aux)             # eta = 0: hands out eps_u, eps_c (and the gradient)
+        got = smp.step(lat, i, text, rep_dev, eta=0.6, variance_noise=z.to(dev))
+        eu, ec = to_lat(aux["eps_u"], 1, F, H, W), to_lat(aux["eps_c"], 1, F, H, W)
+        eps = ec + HP["cfg_scale"] * (ec - eu)
+        want = G.ddim_step_general(G.alphas_cumprod(), torch.tensor(G.FINAL_ALPHA_CUMPROD), ts, i, eps, lat.float().cpu(),
+                                   eta=0.6, variance_noise=z.float(), score=aux["grad"].float().cpu() if i < Gs else None,
+                                   guidance_scale=smp.score_gs)[0]
+        assert rel_err(got, want) < 5e-3
+        assert rel_err(got, plain0) > 1e-3    # and it is not the eta = 0 update (sigma_t is small late in the schedule)
+    i = Gs
+    drawn = smp.step(lat, i, text, rep_dev, eta=0.6, generator=torch.Generator(device=dev).manual_seed(21))
+    z2 = torch.randn(lat.shape, generator=torch.Generator(device=dev).manual_seed(21), device=dev, dtype=lat.dtype)
+    assert torch.equal(drawn, smp.step(lat, i, text, rep_dev, eta=0.6, variance_noise=z2))
+    with pytest.raises(ValueError, match="Cannot pass both generator and variance_noise"):
+        smp.step(lat, i, text, rep_dev, eta=0.6, variance_noise=z2, generator=torch.Generator(device=dev))
