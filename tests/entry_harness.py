@@ -270,12 +270,13 @@ def install_recorders(rec):
     UNet3DConditionModel.forward = forward
     step = MotionCloneSampler.step
 
-    def rstep(self, latents, i, text, rep_dev, aux=None, ctrl=None):
+    def rstep(self, latents, i, text, rep_dev, aux=None, ctrl=None, **kw):
         if i == 0:
             rec["loop"] = dict(lat0=latents.detach().clone(), text=text.detach().clone(), timesteps=[int(t) for t in self.timesteps],
                                G=self.G, ctrl=None if ctrl is None else {k: (v.detach().clone() if torch.is_tensor(v) else v)
                                                                          for k, v in ctrl.items()})
-        out = step(self, latents, i, text, rep_dev, aux=aux, ctrl=ctrl)
+        assert not kw.get("eta"), "the entry scripts sample with eta = 0"
+        out = step(self, latents, i, text, rep_dev, aux=aux, ctrl=ctrl, **kw)
         rec["loop"]["last"] = out.detach().clone()
         rec["loop"]["steps_run"] = i + 1
         return out
