@@ -18,6 +18,17 @@ EMU_DIR = os.path.join(REPO, "tests", "hipemu")
 EMU_LIB = os.path.join(EMU_DIR, "_build", "libmc_emu.so")
 
 
+# -fno-slp-vectorize: no packed fp32 VALU instructions (v_pk_fma_f32 ...).  Measured: the temporal-attention backward is
+# not bit-reproducible with them when MFMA waves of another stream share its SIMDs (csrc/temporal.hip header,
+# tools/tattn_race.py, tests/test_determinism.py), and the library is 1.4 % faster end to end without them (a v_pk_fma_f32
+# costs two v_fma_f32 issue slots beside MFMAs anyway).
+HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
+             "-fno-slp-vectorize"]
+# TEST ONLY: csrc/temporal.hip with the SLP vectoriser ON = the build whose backward went wrong in round 2; the negative
+# control of tests/test_determinism.py (never loaded by the package)
+SLP_CONTROL_LIB = os.path.join(REPO, "tools", "_build", "libtattn_slp.so")
+
+
 def _stamp(paths, extra=""):
     h = hashlib.sha1(extra.encode())
     for p in sorted(paths):
@@ -41,11 +52,7 @@ def _deps():
 def build_hip(force=False, verbose=False):
     """Compile every HIP source for gfx950 and link csrc/libmotionclone_hip.so."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    # -fno-slp-vectorize: no packed fp32 VALU instructions (v_pk_fma_f32 ...).  Measured: the temporal-attention backward was
-    # not bit-reproducible with them when MFMA waves of another stream shared its SIMDs (csrc/temporal.hip header), and the
-    # library is 1.4 % faster end to end without them (a v_pk_fma_f32 costs two v_fma_f32 issue slots beside MFMAs anyway).
-    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
-             "-fno-slp-vectorize"]
+    flags = HIP_FLAGS
     stamp = _stamp(_deps(), " ".join(flags))
     stamp_file = HIP_LIB + ".stamp"
     if not force and os.path.exists(HIP_LIB) and os.path.exists(stamp_file):
@@ -67,6 +74,22 @@ def build_hip(force=False, verbose=False):
     with open(stamp_file, "w") as f:
         f.write(stamp)
     return HIP_LIB
+
+
+def build_slp_control(force=False):
+    """TEST ONLY: the negative control of the determinism stress test (temporal.hip with SLP vectorisation)."""
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, "temporal.hip")
+    flags = [f for f in HIP_FLAGS if f != "-fno-slp-vectorize"]
+    stamp = _stamp([src, os.path.join(CSRC, "mc_common.hpp")], " ".join(flags))
+    stamp_file = SLP_CONTROL_LIB + ".stamp"
+    if not force and os.path.exists(SLP_CONTROL_LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
+        return SLP_CONTROL_LIB
+    os.makedirs(os.path.dirname(SLP_CONTROL_LIB), exist_ok=True)
+    _run([hipcc] + flags + ["-shared", "-o", SLP_CONTROL_LIB, src])
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return SLP_CONTROL_LIB
 
 
 def build_emu(force=False):

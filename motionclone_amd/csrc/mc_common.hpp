@@ -175,7 +175,12 @@ __device__ __forceinline__ void raw_barrier() {
 // instead of being hoisted out of a long loop and kept (or spilled) in VGPRs for its whole duration.
 #ifdef MC_EMU
 __device__ inline int opaque(int x) { return x; }
+__device__ inline float opaque(float x) { return x; }
 #else
+__device__ __forceinline__ float opaque(float x) {
+    asm volatile("" : "+v"(x));
+    return x;
+}
 __device__ __forceinline__ int opaque(int x) {
     asm volatile("" : "+v"(x));
     return x;

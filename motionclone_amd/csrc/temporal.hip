@@ -31,6 +31,10 @@ namespace mc {
 // (build.py); it is also 1.4 % faster end to end.
 __device__ __forceinline__ f32x4 mfma16z(half4_t a, half4_t b, f32x4 c) { return mfma16k32(cat4(a, zero4()), cat4(b, zero4()), c); }
 
+#ifndef MC_TATTN_PROBE
+#define MC_TATTN_PROBE 0
+#endif
+
 struct TParams {
     const half_t* q;
     const half_t* k;
@@ -377,9 +381,18 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
                 float pv = expf(sT[tq][tk][i] - m) / l;
                 float d = dpT[tq][tk][i];
                 if (kv == idxq[tq]) d += seed_coef * (pv - refq[tq]);
+#if MC_TATTN_PROBE & 1   // tools/tattn_race.py: which packed-fp32 chain of an SLP build goes wrong (see header)
+                pv = opaque(pv);
+#endif
+#if MC_TATTN_PROBE & 2
+                d = opaque(d);
+#endif
                 sT[tq][tk][i] = pv;
                 dpT[tq][tk][i] = d;
                 dsum += pv * d;
+#if MC_TATTN_PROBE & 4
+                dsum = opaque(dsum);
+#endif
             }
         Dq[tq] = group_sum(dsum);
     }
@@ -471,6 +484,7 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
 __global__ void reduce_sum_kernel(const float* in, long n, float scale, float* out) {
     __shared__ float red[4];
     float acc = 0.f;
+#pragma clang loop vectorize(disable)   // no packed-fp32 adds (tests/test_determinism.py), one fixed summation order
     for (long i = threadIdx.x; i < n; i += blockDim.x) acc += in[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;

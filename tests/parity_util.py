@@ -15,18 +15,23 @@ from oracle import guidance_ref as G
 from oracle import unet3d_ref as U
 
 HP = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10)
-TOL_FWD, TOL_GRAD, TOL_LOSS = 2e-2, 5e-2, 3e-2      # relative L2 (fp16 storage vs fp32 oracle); loss relative
-TIE_GAP = 4e-3                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
+# Relative L2, fp16 storage vs the fp32 oracle.  Round 3: set at 3-4x what is measured on MI355X (forward / latents 1.1e-3 ..
+# 1.8e-3, gradient 6.4e-3 .. 7.6e-3, loss 1e-4 .. 3.3e-4, tie gap <= 3e-4, flips <= 0.31 % of the rows) so that a 3x regression
+# fails; the counts move by a few rows from run to run of the ORACLE (its fp32 GEMMs pick different split-K orders per shape).
+TOL_FWD, TOL_GRAD, TOL_LOSS = 5e-3, 2e-2, 2e-3
+TIE_GAP = 1e-3                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
+MAX_FLIP_FRACTION = 5e-3
+REPORT_FILE = "parity_r03.json"
 
 _REPORT = {}
 
 
 def report(key, **vals):
-    """collect measured errors; written to gpurun_out/parity_r02.json (copied into DESIGN.md 4 by hand)"""
+    """collect measured errors; written to gpurun_out/<REPORT_FILE> (copied into profiles/ and DESIGN.md 4 by hand)"""
     _REPORT.setdefault(key, {}).update({k: (float(v) if hasattr(v, "__float__") else v) for k, v in vals.items()})
     try:
         os.makedirs("gpurun_out", exist_ok=True)
-        with open(os.path.join("gpurun_out", "parity_r02.json"), "w") as f:
+        with open(os.path.join("gpurun_out", REPORT_FILE), "w") as f:
             json.dump(_REPORT, f, indent=1, sort_keys=True)
     except OSError:
         pass
@@ -119,7 +124,7 @@ def check_extraction(eng, smp, sdo, cfg, vid, noise, text, key, ctrl=None, res=N
            extraction_value_abs_max_err=worst_val)
     assert worst_gap <= TIE_GAP, "an arg-max flip that is not a tie: gap %g" % worst_gap
     assert worst_val < 5e-3
-    assert flips <= 0.02 * total
+    assert flips <= MAX_FLIP_FRACTION * total, (flips, total)
     return rep, ref, prob
 
 
@@ -162,14 +167,17 @@ def check_plain_step(eng, smp, sdo, cfg, lat, text, step_index, key, ctrl=None, 
     return nxt, ref_nxt
 
 
-def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol):
-    """N-step loop (sample_video, motionclone_functions.py:164-166): each side follows its own trajectory"""
+def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=None, start_ref=None):
+    """Steps [first, last) of the loop (sample_video, motionclone_functions.py:164-166): engine and oracle each follow
+    their OWN trajectory from a common start (`start_ref`: fp32 latents at step `first`, default the initial noise)."""
     ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
     hp = dict(HP, guidance_steps=smp.G)
     rep_dev = eng.prepare_representation(rep_ref)
-    x, xr = lat, lat.float()
+    last = smp.N if last is None else last
+    xr = lat.float() if start_ref is None else start_ref.float()
+    x = xr.half()
     drift = []
-    for i in range(smp.N):
+    for i in range(first, last):
         x = smp.step(x, i, text, rep_dev)
         with oracle_mode(lat.device):
             if i < smp.G:
@@ -177,7 +185,7 @@ def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol):
             else:
                 xr, _ = G.plain_step_full(sdo, cfg, xr, i, ts, text.float(), hp["cfg_scale"])
         drift.append(rel(x, xr))
-    report(key, loop_drift=[round(d, 6) for d in drift], loop_steps=smp.N, loop_guided=smp.G)
+    report(key, loop_drift=[round(d, 6) for d in drift], loop_steps=[first, last], loop_schedule=[smp.N, smp.G])
     assert torch.isfinite(x.float()).all()
-    assert drift[-1] < tol, drift
+    assert max(drift) < tol, drift
     return drift

@@ -8,9 +8,14 @@ convolutions use PyTorch's im2col + GEMM path, see parity_util.oracle_mode).
   config 5 shape  32 f x 96 x 96 latent (768^2)                          - B = 1 forward (two 16-wide frame tiles)
   second witness  the oracle in fp16 on the GPU (= the reference's own arithmetic through stock PyTorch-ROCm)
 
+  config 2 trajectory  steps 14 .. 21 of the (30, 18, 0.4) schedule: 4 guided + 4 plain steps across the switch
+  F = 32 (config 5)    32 f x 32 x 32 and 32 f x 48 x 48 latents: forward, extraction, guided (two-tile temporal backward,
+                       guidance seed at (F = 32, d = 160)), plain and last step
+
 Weights: synthetic seed 1234 with motion proj_out re-randomised; both sides use the same fp16-rounded
-parameters.  Tolerances (parity_util): forward / latents 2e-2 relative L2, gradient 5e-2, loss 3 %, arg-max flips
-must be ties (oracle gap <= 4e-3) and are counted exactly.  Measured errors are written to gpurun_out/parity_r02.json.
+parameters.  Tolerances (parity_util, 3-4x the measured errors): forward / latents 5e-3 relative L2, gradient 2e-2, loss 0.2 %,
+arg-max flips must be ties (oracle gap <= 1e-3), at most 0.5 % of the rows, and are counted exactly.  Measured errors are
+written to gpurun_out/parity_r03.json.
 """
 import pytest
 import torch
@@ -67,7 +72,39 @@ def test_full_loop_config1(world):
     smp = sampler(eng, 10, 5, 0.3)
     with PU.oracle_mode(dev):
         rep_ref = G.extract_representation(sdo, cfg, vid.float(), noise.float(), text[0:1].float())
-    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg1_16f_256", tol=5e-2)
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg1_16f_256", tol=6e-3)
+    torch.cuda.empty_cache()
+
+
+def test_trajectory_config2_across_the_guided_plain_switch(world):
+    """config 2 (30 steps, 18 guided): 8 CONSECUTIVE steps 14 .. 21 - the last four guided steps (cool-down scaling
+    active: i > 18 - 10) and the first four plain ones - engine and oracle each on their own trajectory from a common
+    latent (the seeded initial latent, entered at step 14: any finite latent is a valid state of the sampler)."""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 16, 64, 64
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 30, 18, 0.4)
+    with PU.oracle_mode(dev):
+        rep_ref = G.extract_representation(sdo, cfg, vid.float(), noise.float(), text[0:1].float())
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg2_trajectory", tol=6e-3, first=14, last=22)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("hw", [32, 48])
+def test_32_frames_forward_extraction_guided_plain(world, hw):
+    """BASELINE config 5 has F = 32 (the PE table's maximum, motion_module.py:60): temporal attention runs as two 16-frame
+    tiles per side, the backward's F > 16 path, the guidance seed and top-1 at (F = 32, d = 160), the tape at that size.
+    Spatial size reduced to what the fp32 oracle's autograd fits comfortably; schedule (50, 30, 0.4) as config 5."""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 32, hw, hw
+    key = "cfg5_32f_%d" % (8 * hw)
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 50, 30, 0.4)
+    PU.check_forward_b2(eng, sdo, cfg, lat, text, int(smp.timesteps[0]), key)
+    _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key)
+    nxt2, _ = PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
+    PU.check_plain_step(eng, smp, sdo, cfg, nxt2, text, smp.N - 1, key)
     torch.cuda.empty_cache()
 
 

@@ -384,7 +384,7 @@ def _temporal_unref(t, B, F_, HW, heads, d):  # [B*HW, heads, F, d] -> [(b f hw)
     return t.reshape(B, HW, heads, F_, d).permute(0, 3, 1, 2, 4).reshape(B * F_ * HW, heads * d)
 
 
-@pytest.mark.parametrize("F_,d", [(16, 40), (5, 16), (16, 160), (24, 32), (32, 80)])
+@pytest.mark.parametrize("F_,d", [(16, 40), (5, 16), (16, 160), (24, 32), (32, 80), (32, 160), (32, 40)])
 def test_temporal_attention_and_guidance(backend, F_, d):
     dev = backend
     B, HW, heads = (2, 6, 2) if not big(dev) else (2, 300, 8)
@@ -507,7 +507,7 @@ def test_video_resize(backend):
     assert torch.equal(preprocess_frames(x.numpy(), 32, 48, device=dev), got)
 
 
-@pytest.mark.parametrize("F_,d", [(16, 160), (16, 40), (24, 32)])
+@pytest.mark.parametrize("F_,d", [(16, 160), (16, 40), (24, 32), (32, 160), (32, 40)])
 def test_top1_follows_the_reference_fp16_order_bit_exactly(backend, F_, d):
     """obtain_motion_representation in the reference's own arithmetic (attention.py:593-609, motionclone_functions.py:79):
     scores rounded to fp16 -> fp32 softmax -> probabilities rounded to fp16 -> topk(k=1) on the fp16 values.  Checked
