@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
-SOURCES = ["gemm_api.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
+SOURCES = ["gemm_api.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "gemm5.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
 HIP_LIB = os.path.join(CSRC, "libmotionclone_hip.so")
 EMU_DIR = os.path.join(REPO, "tests", "hipemu")
 EMU_LIB = os.path.join(EMU_DIR, "_build", "libmc_emu.so")

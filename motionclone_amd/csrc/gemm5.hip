@@ -1,0 +1,418 @@
+// GEMM / implicit-conv kernel, third generation of the 256x320 tile (contract: gemm_params.hpp, as gemm3.hip).
+//
+// What round 2 measured on gemm3: a k-step of the 2-stage loop takes ~4400 cycles against 2560 cycles of MFMA
+// work per SIMD, because after every __syncthreads() both waves of a SIMD issue their 9 LDS-DMA instructions (~100 issue
+// cycles each) at the same time and only then start their MFMAs, and the fp32 LDS staging epilogue (two waves writing,
+// six waiting, four passes) costs ~7 us of a 40 us K = 640 tile.  This kernel keeps the tile (8 waves as 4 x 2, wave tile
+// 64 x 160 of v_mfma_f32_32x32x16_f16, BN = 320 = the UNet's width quantum) and changes the two things that idle the pipe:
+//
+//  * K loop: a RING OF FOUR 32-deep operand stages (4 x 36 KiB), one raw s_barrier per stage, counted s_waitcnt vmcnt:
+//    the loads of stage j+3 / j+4 are in flight while stage j is multiplied, nothing is drained at a barrier.  A stage is
+//    two 16-deep k-slices; the barrier sits BETWEEN them: before it a wave has already fetched the fragments of slice 1,
+//    after it it issues slice 1's MFMAs while the fragments of the next stage's slice 0 arrive - the matrix pipe has work
+//    on both sides of every barrier.  The LDS-DMA issue is interleaved with the MFMAs one instruction at a time and
+//    STAGGERED between the two waves of a SIMD: waves 0-3 (one per SIMD) issue theirs in the first half of a stage,
+//    waves 4-7 in the second half, so a SIMD always has one wave that is only feeding the matrix pipe.
+//  * Epilogue: every wave drains its own accumulators (no workgroup barrier, no idle waves): bias / alpha in fp32 in the
+//    accumulator layout, fp16 through a WAVE-PRIVATE LDS image (row pitch 336 B: at most 2-way on the 8-byte transposing
+//    writes), read back as whole 320-byte row segments and stored 16 bytes per lane with the residual added on the way
+//    (R is rounded like the reference rounds it: Linear output to fp16, then the add - attention.py:293-299).
+//
+// Everything else is gemm3's: operand tiles global -> LDS by LDS-DMA with the XOR swizzle on the source address,
+// hardware zero fill for conv padding / tails, K order of the convs (64-channel tile major, tap minor), XCD-aware tile
+// order.  Split-K and odd shapes (N % 8, ldc % 8) stay on gemm3.
+#include "gemm_params.hpp"
+#include <type_traits>
+
+namespace mc {
+
+namespace g5 {
+constexpr int BM = 256, BN = 320, NW = 8, NT = 512, TM = 2, TN = 5, BKT = 32, NS = 4;
+constexpr int ROWB = 64;                 // bytes per staged row (32 halfs)
+constexpr int RPI = 16;                  // rows moved by one LDS-DMA instruction
+constexpr int STAGE = (BM + BN) * ROWB;  // 36864
+constexpr int A_BYTES = BM * ROWB;
+constexpr int LA = 5, LB = 4;            // LDS-DMA instructions per stage: waves 0-3 (2 A + 3 W) / waves 4-7 (2 A + 2 W)
+constexpr int RS = 336;                  // row pitch of the epilogue's fp16 image (bytes)
+constexpr int RSG = 176;                 // same, fused GEGLU (80 outputs per row)
+constexpr int STG = 32 * RS;             // one 32-row half of a wave's tile
+constexpr size_t SMEM = (size_t)NS * STAGE;
+static_assert(NW * STG <= NS * STAGE, "epilogue image must fit the ring");
+
+__device__ __forceinline__ int lds_off32(int row, int v) { return row * 64 + ((v ^ ((row >> 2) & 3)) << 4); }
+}  // namespace g5
+
+// VAR (timing experiments, tools/gemm5_bench.py): bit 0 = no stagger (every wave issues its loads in the first half),
+// bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
+template <int MODE, int EPI, int VAR>
+__global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2, uint32_t bytesW,
+                                                        int tilesM, int tilesN) {
+    using namespace g5;
+    MC_DYN_SMEM(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef MC_EMU
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches on the wave group
+#endif
+    const bool grpA = wave < 4;
+    const int pid = blockIdx.x;
+    const int xcd = pid & 7, local = pid >> 3;
+    const int tn = local % tilesN;
+    int tm;   // tile order: see gemm3.hip
+    if (MODE == DENSE || tilesN > 1) {
+        tm = (local / tilesN) * 8 + xcd;
+    } else {
+        const int per = (tilesM + 7) >> 3;
+        tm = (local / tilesN) < per ? xcd * per + local / tilesN : tilesM;
+    }
+    if (tm >= tilesM) return;
+    const int m0 = tm * BM, n0 = tn * BN;
+
+    const GBuf bufA = make_gbuf(p.A, bytesA);
+    const GBuf bufA2 = make_gbuf(p.A2 ? p.A2 : p.A, p.A2 ? bytesA2 : bytesA);
+    const GBuf bufW = make_gbuf(p.W, bytesW);
+
+    // lane -> (row within the instruction's 16-row group, physical 16-byte slot); logical slot undoes the swizzle
+    const int rsub = lane >> 2;
+    const int lslot = (lane & 3) ^ (lane >> 4);
+
+    int a_valid[2], a_pix[2], a_oy[2], a_ox[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        int m = m0 + (wave + NW * i) * RPI + rsub;
+        a_valid[i] = m < p.M;
+        if (MODE == DENSE) {
+            a_pix[i] = m;
+            a_oy[i] = a_ox[i] = 0;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int fr = m / hw;
+            int rem = m - fr * hw;
+            int oy = rem / p.Wo;
+            a_pix[i] = fr * p.Hs * p.Ws;
+            a_oy[i] = oy;
+            a_ox[i] = rem - oy * p.Wo;
+        }
+    }
+    // weight row groups: 20 per stage; wave w takes w, w + 8 and (waves 0-3) 16 + w
+    uint32_t w_off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        int n = n0 + (i < 2 ? wave + NW * i : 16 + (wave & 3)) * RPI + rsub;
+        w_off[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)lslot * 16u : kOOB;
+    }
+
+    // one LDS-DMA instruction of stage tile kt: piece 0,1 = activation row groups, 2,3,4 = weight row groups
+    auto issue_piece = [&](int kt, int buf, int piece) {
+        char* base = smem + buf * STAGE;
+        if (piece < 2) {
+            const int i = piece;
+            int tap = 0, c0 = kt * BKT;
+            if (MODE != DENSE) {   // K order: 64-channel tile major, tap minor; a stage is half a 64-channel tile
+                const int kt64 = kt >> 1;
+                const int ct = kt64 / 9;
+                tap = kt64 - 9 * ct;
+                c0 = ct * 64 + (kt & 1) * 32;
+            }
+            const bool second = c0 >= p.c1;
+            const int ld = second ? p.lda2 : p.lda;
+            const int cc = (second ? c0 - p.c1 : c0) + lslot * 8;
+            const int ky = tap / 3, kx = tap - 3 * (tap / 3);
+            bool ok = a_valid[i];
+            int row;
+            if (MODE == DENSE) {
+                row = a_pix[i];
+            } else {
+                int iy, ix;
+                if (MODE == CONV_S1) {
+                    iy = a_oy[i] + ky - 1;
+                    ix = a_ox[i] + kx - 1;
+                    ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                } else if (MODE == CONV_S2) {
+                    iy = 2 * a_oy[i] + ky - p.s2_pad;
+                    ix = 2 * a_ox[i] + kx - p.s2_pad;
+                    ok = ok && iy >= 0 && iy < p.Hs && ix >= 0 && ix < p.Ws;
+                } else if (MODE == CONV_UP) {
+                    int uy = a_oy[i] + ky - 1, ux = a_ox[i] + kx - 1;
+                    ok = ok && uy >= 0 && uy < p.Ho && ux >= 0 && ux < p.Wo;
+                    iy = uy >> 1;
+                    ix = ux >> 1;
+                } else {
+                    int ty = a_oy[i] + 1 - ky, tx = a_ox[i] + 1 - kx;
+                    ok = ok && ty >= 0 && tx >= 0 && !(ty & 1) && !(tx & 1);
+                    iy = ty >> 1;
+                    ix = tx >> 1;
+                    ok = ok && iy < p.Hs && ix < p.Ws;
+                }
+                row = a_pix[i] + iy * p.Ws + ix;
+            }
+            // out of range (padding, M tail): top bit set = beyond every descriptor = hardware zero fill; no branch
+            uint32_t voff = (((uint32_t)row * (uint32_t)ld + (uint32_t)cc) * 2u) | (ok ? 0u : kOOB);
+            char* dst = base + (wave + NW * i) * 1024;
+            if (second)
+                glds16(bufA2, voff, dst);
+            else
+                glds16(bufA, voff, dst);
+        } else {
+            const int i = piece - 2;
+            uint32_t voff = w_off[i] + (uint32_t)kt * (BKT * 2u);   // kOOB + a small offset stays out of range
+            glds16(bufW, voff, base + A_BYTES + (i < 2 ? wave + NW * i : 16 + (wave & 3)) * 1024);
+        }
+    };
+    auto issue_stage = [&](int kt, int buf) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) issue_piece(kt, buf, q);
+        if (grpA) issue_piece(kt, buf, 4);
+    };
+    // wait until at most `tiles` (0..2) of this wave's staged tiles are still in flight (loads retire in order)
+    auto wait_tiles = [&](int tiles) {
+        if (tiles <= 0) {
+            wait_vmcnt_le<0>();
+        } else if (tiles == 1) {
+            if (grpA) wait_vmcnt_le<LA>(); else wait_vmcnt_le<LB>();
+        } else {
+            if (grpA) wait_vmcnt_le<2 * LA>(); else wait_vmcnt_le<2 * LB>();
+        }
+    };
+
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wr = wave & 3, wc = wave >> 2;
+    const int wm0 = wr * 64, wn0 = wc * 160;
+    const int l31 = lane & 31, lhi = lane >> 5;
+
+    const int split = blockIdx.y;
+    const int nk_all = p.K / BKT;
+    const int kt_begin = (int)((long)split * nk_all / p.splits);
+    const int nk = (int)((long)(split + 1) * nk_all / p.splits);
+
+    // prologue: waves 0-3 put stages 0..2 in flight, waves 4-7 stages 0..3 (they issue stage j + 4 in the second half of j)
+    const bool stagger = !(VAR & 1);
+    const int nst = nk - kt_begin;
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0)
+        if (s0 < nst) issue_stage(kt_begin + s0, s0);
+    if (stagger && !grpA && 3 < nst) issue_stage(kt_begin + 3, 3);
+
+    half8_t fa[2][TM], fw[2][TN];   // slot 0: k-slice 0 of a stage, slot 1: k-slice 1
+    auto load_frags = [&](int buf, int ks, half8_t* a, half8_t* w) {
+        const char* bA = smem + buf * STAGE;
+        const char* bW = bA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            a[j] = *reinterpret_cast<const half8_t*>(bA + lds_off32(wm0 + 32 * j + l31, 2 * ks + lhi));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            w[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * ks + lhi));
+    };
+    // Half a stage = one scheduling region: the 10 MFMAs of the current k-slice (`ca / cw`), the 7 fragment reads of the
+    // NEXT one (into `ra / rw`) and NL LDS-DMA instructions of stage `lkt` (ring slot `lbuf`), in this order:
+    //   read a'0, a'1;  then for each weight fragment i:  MFMA (i,0), MFMA (i,1), read w'i, [one LDS-DMA]
+    // A weight fragment is dead after its two MFMAs, so w'i can take its registers: 5 + 2 x 2 fragments live instead of
+    // 2 x 7 (the 256-register budget holds 160 accumulators), and no instruction kind is issued in a burst.
+    auto half_step = [&](auto nl_tag, int rbuf, int rks, half8_t* ra, half8_t* rw, const half8_t* ca, const half8_t* cw,
+                         int lkt, int lbuf) {
+        constexpr int NL = decltype(nl_tag)::value;
+        const char* bA = smem + rbuf * STAGE;
+        const char* bW = bA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            ra[j] = *reinterpret_cast<const half8_t*>(bA + lds_off32(wm0 + 32 * j + l31, 2 * rks + lhi));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(cw[i], ca[j], acc[i][j]);
+            rw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * rks + lhi));
+            if (i < NL) issue_piece(lkt, lbuf, i);
+        }
+#ifndef MC_EMU
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);          // DS read: a'0, a'1
+        if (NL > 0 && (VAR & 2)) __builtin_amdgcn_sched_group_barrier(0x010, NL, 0);   // experiment: LDS-DMA burst at the top
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);      // MFMA (i, 0), (i, 1)
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read w'i
+            if (!(VAR & 2) && i < NL) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA
+        }
+#endif
+    };
+    using N0 = std::integral_constant<int, 0>;
+    using N4 = std::integral_constant<int, 4>;
+    using N5 = std::integral_constant<int, 5>;
+
+    // stage 0 landed: this wave's own loads (counted: waves 4-7 may have three younger stages in flight), then everybody's
+    {
+        const int younger = min(stagger && !grpA ? 3 : 2, nst - 1);
+        if (younger >= 3) wait_vmcnt_le<3 * LB>(); else wait_tiles(younger);
+    }
+    raw_barrier();
+    load_frags(0, 0, fa[0], fw[0]);
+
+    // The loop is written out per wave group and per phase (steady state / tail) so that each body is one straight-line
+    // scheduling region with a fixed instruction mix; every version executes exactly one barrier per stage.
+    int buf = 0, kt = kt_begin;
+    if (grpA) {
+        // steady state of waves 0-3: stage kt + 3 goes into the slot freed at the previous barrier
+        for (; kt + 3 < nk; ++kt) {
+            const int nbuf = (buf + 1) & 3;
+            half_step(N5(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
+            // stage kt + 1 landed (own loads: counted wait, two younger stages stay in flight; everybody's: barrier).  Past
+            // the barrier every wave has also finished reading stage kt (slice-1 fragments are in registers)
+            wait_vmcnt_le<2 * LA>();
+            raw_barrier();
+            half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
+            buf = nbuf;
+        }
+    } else if (!stagger) {
+        // experiment (VAR bit 0): waves 4-7 issue in the first half like waves 0-3
+        for (; kt + 3 < nk; ++kt) {
+            const int nbuf = (buf + 1) & 3;
+            half_step(N4(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
+            wait_vmcnt_le<2 * LB>();
+            raw_barrier();
+            half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
+            buf = nbuf;
+        }
+    } else {
+        // steady state of waves 4-7: stage kt + 4 goes into slot `buf` right after the barrier that frees it
+        for (; kt + 4 < nk; ++kt) {
+            const int nbuf = (buf + 1) & 3;
+            half_step(N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
+            wait_vmcnt_le<2 * LB>();
+            raw_barrier();
+            half_step(N4(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + 4, buf);
+            buf = nbuf;
+        }
+    }
+    // tail: nothing left to issue (the next stage's slice-0 fragments read after the last stage are stale and never used)
+    for (; kt < nk; ++kt) {
+        const int nbuf = (buf + 1) & 3;
+        half_step(N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
+        wait_tiles(min(2, nk - 2 - kt));
+        raw_barrier();
+        half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
+        buf = nbuf;
+    }
+    // every wave passed the last barrier after its final LDS read and no load is in flight: the ring is free
+
+    // ---- epilogue: wave-private, two 32-row halves ----
+    char* stg = smem + wave * STG;
+    constexpr int SEGS = EPI == 1 ? 10 : 20;          // 16-byte segments per image row
+    constexpr int PITCH = EPI == 1 ? RSG : RS;
+    constexpr int RPI_OUT = 60 / SEGS;                // rows per read-back instruction (60 of 64 lanes)
+    constexpr int NIT = (32 + RPI_OUT - 1) / RPI_OUT;
+    const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == RPI_OUT -> idle
+    const int ncol = EPI == 1 ? (n0 + wn0) / 2 + seg * 8 : n0 + wn0 + seg * 8;   // first output column of the lane's segment
+    const int nout = EPI == 1 ? p.N / 2 : p.N;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int mrow = m0 + wm0 + 32 * j;           // global row of image row 0
+        // residual rows of this half: in flight while the accumulators are converted and transposed
+        half8_t rres[NIT];
+        if (EPI == 0 && p.R) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = it * RPI_OUT + rsel, m = mrow + r;
+                if (rsel < RPI_OUT && r < 32 && m < p.M && ncol < nout) rres[it] = ld8(p.R + (size_t)m * p.ldr + ncol);
+            }
+        }
+        // accumulators (lane: row l31, 4 consecutive columns per (i, q)) -> + bias, * alpha -> fp16 image
+        const int mlane = mrow + l31;
+        const float* brow = p.bias ? p.bias + (size_t)(min(mlane, p.M - 1) / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = 32 * i + 8 * q + 4 * lhi;   // column within the wave's 160
+                const int n = n0 + wn0 + cl;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (brow && n < p.N) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(brow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                }
+                if (EPI == 1) {   // fused GEGLU: columns are (h, gate) pairs
+                    half2_t o;
+                    o[0] = to_half(v[0] * gelu_f(v[1]));
+                    o[1] = to_half(v[2] * gelu_f(v[3]));
+                    *reinterpret_cast<half2_t*>(stg + l31 * PITCH + cl) = o;
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + cl * 2) = o;
+                }
+            }
+        }
+        wave_lds_sync();
+        // image rows -> global: 16 bytes per lane, whole row segments of the wave's columns
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel, m = mrow + r;
+            if (rsel < RPI_OUT && r < 32 && m < p.M && ncol < nout) {
+                half8_t o = *reinterpret_cast<const half8_t*>(stg + r * PITCH + seg * 16);
+                if (EPI == 0 && p.R) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half((float)o[e] + (float)rres[it][e]);
+                }
+                st8(p.C + (size_t)m * p.ldc + ncol, o);
+            }
+        }
+        wave_lds_sync();   // the image is rewritten by the next half
+    }
+}
+
+template <int MODE, int EPI, int VAR>
+static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
+    int tM = (p.M + g5::BM - 1) / g5::BM, tN = (p.N + g5::BN - 1) / g5::BN;
+    allow_big_smem(gemm5_kernel<MODE, EPI, VAR>, g5::SMEM);
+    dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN), (unsigned)p.splits);
+    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR>), grid, dim3(g5::NT), g5::SMEM, stream, p, bA, bA2, bW, tM, tN);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+template <int MODE>
+static int launch5_var(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, int var, hipStream_t s) {
+    if (p.epi == 1) {
+        if (MODE != DENSE) return MC_ERR_UNSUPPORTED;
+        return launch5<DENSE, 1, 0>(p, bA, bA2, bW, s);
+    }
+    if (var == 0) return launch5<MODE, 0, 0>(p, bA, bA2, bW, s);
+    if constexpr (MODE == DENSE || MODE == CONV_S1) {   // schedule experiments (tools/gemm5_bench.py)
+        if (var == 1) return launch5<MODE, 0, 1>(p, bA, bA2, bW, s);
+        if (var == 2) return launch5<MODE, 0, 2>(p, bA, bA2, bW, s);
+        if (var == 3) return launch5<MODE, 0, 3>(p, bA, bA2, bW, s);
+    }
+    return MC_ERR_UNSUPPORTED;
+}
+
+// Returns MC_ERR_UNSUPPORTED for what stays on gemm3: split-K, N / ldc / ldr not multiples of 8, operands >= 2 GiB.
+int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStream_t stream) {
+    size_t bytesA = (rowsA * (size_t)p.lda) * 2, bytesA2 = p.A2 ? (rowsA * (size_t)p.lda2) * 2 : 0;
+    size_t bytesW = (size_t)p.N * p.K * 2;
+    const size_t lim = 0x7FFFFFF0u;
+    if (bytesA > lim || bytesA2 > lim || bytesW > lim) return MC_ERR_UNSUPPORTED;
+    if (p.ws || p.splits != 1) return MC_ERR_UNSUPPORTED;
+    if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
+    if (p.epi == 1 && (p.N & 15)) return MC_ERR_UNSUPPORTED;
+    switch (mode) {
+        case DENSE: return launch5_var<DENSE>(p, bytesA, bytesA2, bytesW, var, stream);
+        case CONV_S1: return launch5_var<CONV_S1>(p, bytesA, bytesA2, bytesW, var, stream);
+        case CONV_S2: return launch5_var<CONV_S2>(p, bytesA, bytesA2, bytesW, var, stream);
+        case CONV_UP: return launch5_var<CONV_UP>(p, bytesA, bytesA2, bytesW, var, stream);
+        default: return launch5_var<TCONV_S2>(p, bytesA, bytesA2, bytesW, var, stream);
+    }
+}
+
+}  // namespace mc

@@ -1,6 +1,8 @@
 // C entry points of the GEMM / implicit-conv family (include/mc_kernels.h) and the choice of kernel structure:
 //   gemm4.hip  streaming, A-stationary (short-K Linear layers of the 64x64 level, K = 320)
-//   gemm3.hip  256x320 / 128x320 tiles, 8 / 4 waves (everything that still fills the 256 CUs with them), split-K
+//   gemm5.hip  256x320 tiles, 8 waves, 4-stage ring + staggered LDS-DMA + wave-private epilogue (round 3: whatever fills the
+//              256 CUs with 256x320 tiles and is not split-K)
+//   gemm3.hip  256x320 / 128x320 tiles, 8 / 4 waves, 2-stage loop (split-K, 128x320 tiles, odd shapes)
 //   gemm2.hip  128x128 / 64x64 tiles (small problems of the 16x16 / 8x8 levels)
 // All kernels address their operands through 32-bit buffer descriptors (hardware range check = zero fill for conv
 // padding and tails), so an operand must stay below 2 GiB: larger problems are cut into row ranges here.
@@ -10,6 +12,7 @@ namespace mc {
 int gemm2_dispatch(const GemmParams& p, int mode, int small_tile, int deep, size_t rowsA, hipStream_t stream);   // gemm2.hip
 int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStream_t stream);                    // gemm3.hip
 int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream);                                         // gemm4.hip
+int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStream_t stream);                    // gemm5.hip
 }  // namespace mc
 
 using namespace mc;
@@ -37,6 +40,8 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     const int M = p.M, N = p.N;
     const size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (p.Ho * p.Wo)) * p.Hs * p.Ws;
     if (big_cfg == 10) return mode == DENSE ? gemm4_dispatch(p, nsplit, s) : MC_ERR_UNSUPPORTED;
+    if (big_cfg >= 11) return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);   // 11 = the shipped schedule, 12.. = experiments
+    static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
     if (!big_cfg && !tile && !deep) {
         // measured on MI355X (profiles/r02_gemm4_microbench.md): the streaming kernel wins on the K = 320 Linear layers once
         // the problem has >= 256 row blocks of work; the 256x320 / 128x320 tiles win wherever they still fill the 256 CUs;
@@ -51,6 +56,10 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
             if (b1 >= fill_of(224, share)) big_cfg = 1;
             else if (b4 >= fill_of(192, share)) big_cfg = 4;
         }
+    }
+    if (big_cfg == 1 && !no_g5 && !tile && !deep) {
+        int rc5 = gemm5_dispatch(p, mode, 0, rowsA, s);
+        if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
     }
     if (big_cfg) {
         int rc3 = gemm3_dispatch(p, mode, big_cfg, rowsA, s);

@@ -84,6 +84,63 @@ def test_gemm_large_tile_geometries(backend, cfg):
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm3 geglu")
 
 
+@pytest.mark.parametrize("var", [0, 1, 2, 3])
+def test_gemm5_ring_kernel(backend, var):
+    """gemm5.hip (4-stage ring, staggered LDS-DMA, wave-private epilogue), forced with cfg = 11 + schedule variant: dense with
+    per-batch bias / residual / alpha / M and N tails / short and long K (2 .. 40 ring stages), two-source conv, fused GEGLU"""
+    dev = backend
+    cfg = 11 + var
+    for (M, N, K) in ([(300, 328, 64), (260, 640, 192)] if not big(dev) else [(3000, 968, 128), (5000, 640, 1280)]):
+        a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+        bias = torch.randn(2, N, generator=torch.Generator().manual_seed(3)).to(dev)
+        res = rnd((M, N), dev, 4)
+        rpb = (M + 1) // 2
+        out = ops.gemm(a, w, bias=bias, residual=res, alpha=0.5, rows_per_batch=rpb, cfg=cfg)
+        lin = (0.5 * (a.float() @ w.float().t()) + bias.repeat_interleave(rpb, 0)[:M]).half().float()   # rounded, then + R
+        close(out, lin + res.float(), 2e-2, 5e-3, "gemm5 dense %d %d %d" % (M, N, K))
+        out2 = ops.gemm(a, w, cfg=cfg)
+        close(out2, a.float() @ w.float().t(), 2e-2, 5e-3, "gemm5 dense plain")
+    if var:
+        return   # the schedule variants exist for the dense and stride-1 conv kernels only
+    NF, Cin, Cout, H, W = (2, 64, 72, 6, 10) if not big(dev) else (4, 128, 320, 24, 20)
+    x, x2 = rnd((NF, Cin, H, W), dev, 5), rnd((NF, 64, H, W), dev, 6)
+    wc = rnd((Cout, Cin + 64, 3, 3), dev, 7, 0.05)
+    o = ops.gemm(_to_cl(x), _conv_w_pack(wc), a2=_to_cl(x2), mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, cfg=cfg)
+    close(_from_cl(o, NF, H, W), Fn.conv2d(torch.cat([x, x2], 1).float(), wc.float(), padding=1), 3e-2, 5e-3, "gemm5 conv")
+    M, K, D = (300, 128, 80) if not big(dev) else (3000, 320, 640)
+    a = rnd((M, K), dev, 1)
+    wg = rnd((2 * D, K), dev, 8, 0.1)
+    bg = torch.randn(1, 2 * D, generator=torch.Generator().manual_seed(9)).to(dev)
+    y = a.float() @ wg.float().t() + bg
+    og = ops.gemm(a, ops.interleave_geglu(wg), bias=ops.interleave_geglu(bg.t()).t().contiguous(), geglu=True, cfg=cfg)
+    close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm5 geglu")
+
+
+@pytest.mark.parametrize("mode", ["s2", "up", "tconv"])
+def test_gemm5_conv_modes(backend, mode):
+    dev = backend
+    NF, Cin, Cout, H, W = (2, 64, 72, 8, 12) if not big(dev) else (4, 128, 320, 32, 24)
+    x = rnd((NF, Cin, H, W), dev, 5)
+    wc = rnd((Cout, Cin, 3, 3), dev, 7, 0.05)
+    if mode == "s2":
+        o = ops.gemm(_to_cl(x), _conv_w_pack(wc), mode=ops.CONV_S2, geom=(H, W, H // 2, W // 2), m_out=NF * H * W // 4, cfg=11)
+        close(_from_cl(o, NF, H // 2, W // 2), Fn.conv2d(x.float(), wc.float(), stride=2, padding=1), 3e-2, 5e-3, "gemm5 s2")
+    elif mode == "up":
+        o = ops.gemm(_to_cl(x), _conv_w_pack(wc), mode=ops.CONV_UP, geom=(H, W, 2 * H, 2 * W), m_out=NF * 4 * H * W, cfg=11)
+        ref = Fn.conv2d(Fn.interpolate(x.float(), scale_factor=2.0, mode="nearest"), wc.float(), padding=1)
+        close(_from_cl(o, NF, 2 * H, 2 * W), ref, 3e-2, 5e-3, "gemm5 up")
+    else:   # data gradient of a stride-2 conv (Downsample3D's backward)
+        Co = 64 if not big(dev) else 128
+        xg = x.float().requires_grad_()
+        w2 = rnd((Co, Cin, 3, 3), dev, 8, 0.05)
+        y = Fn.conv2d(xg, w2.float(), padding=1, stride=2)
+        dy = rnd(tuple(y.shape), dev, 3)
+        (ref,) = torch.autograd.grad(y, xg, dy.float())
+        wd = ops.pack_conv_k(w2.permute(1, 2, 3, 0).reshape(Cin, 9, Co))
+        o = ops.gemm(_to_cl(dy), wd, mode=ops.TCONV_S2, geom=(y.shape[2], y.shape[3], H, W), m_out=NF * H * W, cfg=11)
+        close(_from_cl(o, NF, H, W), ref, 3e-2, 5e-3, "gemm5 tconv")
+
+
 @pytest.mark.parametrize("splits,cfg", [(2, 0), (3, 4), (5, 1), (4, 5)])
 def test_gemm_split_k(backend, splits, cfg):
     """split-K path: K ranges in separate workgroups -> fp32 partial sums -> reduce kernel with bias / residual"""
