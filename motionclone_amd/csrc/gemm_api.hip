@@ -42,6 +42,8 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     if (big_cfg == 10) return mode == DENSE ? gemm4_dispatch(p, nsplit, s) : MC_ERR_UNSUPPORTED;
     if (big_cfg >= 11) return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);   // 11 = the shipped schedule, 12.. = experiments
     static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
+    static const int g5_var = getenv("MC_GEMM5_VAR") ? atoi(getenv("MC_GEMM5_VAR")) : 0;   // A/B only
+    const bool automatic = !big_cfg && !tile && !deep;   // an explicit cfg = 1 still means gemm3 (tests, A/B tools)
     if (!big_cfg && !tile && !deep) {
         // measured on MI355X (profiles/r02_gemm4_microbench.md): the streaming kernel wins on the K = 320 Linear layers once
         // the problem has >= 256 row blocks of work; the 256x320 / 128x320 tiles win wherever they still fill the 256 CUs;
@@ -57,8 +59,8 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
             else if (b4 >= fill_of(192, share)) big_cfg = 4;
         }
     }
-    if (big_cfg == 1 && !no_g5 && !tile && !deep) {
-        int rc5 = gemm5_dispatch(p, mode, 0, rowsA, s);
+    if (big_cfg == 1 && automatic && !no_g5) {
+        int rc5 = gemm5_dispatch(p, mode, (mode == DENSE || mode == CONV_S1) && !p.epi ? g5_var : 0, rowsA, s);
         if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
     }
     if (big_cfg) {

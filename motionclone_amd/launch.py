@@ -53,6 +53,27 @@ def _set_arg(argv, name, value):
     return out + [name, str(value)]
 
 
+def _condition_images_are_encoded(inference_config):
+    """True iff the SparseCtrl variant named by the inference config's `controlnet_config` uses the simplified (latent)
+    condition embedding.  Read with yaml (OmegaConf files are plain yaml); a config that cannot be read counts as the
+    latent variant, the reference's i2v_rgb default."""
+    try:
+        import yaml
+        with open(inference_config) as f:
+            cfg = yaml.safe_load(f) or {}
+        cpath = cfg.get("controlnet_config")
+        if not cpath:
+            return True
+        if not os.path.isabs(cpath) and not os.path.exists(cpath):
+            cpath = os.path.join(os.path.dirname(os.path.abspath(inference_config)), os.pardir, cpath)
+        with open(cpath) as f:
+            ccfg = yaml.safe_load(f) or {}
+        kw = ccfg.get("controlnet_additional_kwargs", ccfg)
+        return bool(kw.get("use_simplified_condition_embedding", True))
+    except (OSError, ValueError, AttributeError, ImportError):
+        return True
+
+
 class _ShardedLines(io.StringIO):
     """file object over the examples file that yields only this rank's lines; before each of them it burns the global-RNG
     draws of the lines skipped since the previous one (see module docstring)"""
@@ -83,8 +104,16 @@ def main(argv=None):
         i = argv.index("--vae-scale")
         del argv[i:i + 2]
     script, sargv = argv[0], argv[1:]
+    # Pin the GPU BEFORE anything initialises the HIP runtime: the runtime reads CUDA_VISIBLE_DEVICES once, and both
+    # torch.cuda.is_available() and the scripts' own late `os.environ["CUDA_VISIBLE_DEVICES"] = args.visible_gpu` (inside
+    # main()) come after it otherwise - every rank would then sit on device 0 and RCCL would refuse the duplicate devices.
+    local = int(os.environ.get("LOCAL_RANK", os.environ.get("RANK", "0")))
+    multi = int(os.environ.get("WORLD_SIZE", "1")) > 1
+    if multi and os.environ.get("MC_LAUNCH_NO_PIN", "0") != "1":
+        visible = os.environ.get("CUDA_VISIBLE_DEVICES")
+        ids = [v for v in visible.split(",") if v] if visible else None
+        os.environ["CUDA_VISIBLE_DEVICES"] = ids[local % len(ids)] if ids else str(local)
     rank, world = mcd.init()
-    local = int(os.environ.get("LOCAL_RANK", rank))
     is_i2v = "i2v" in os.path.basename(script)
     examples = _arg(sargv, ["--examples"], "configs/i2v_sketch.jsonl" if is_i2v else "configs/t2v_camera.jsonl")
     rep_dir = _arg(sargv, ["--motion-representation-save-dir"], "motion_representation/")
@@ -96,12 +125,20 @@ def main(argv=None):
     if world > 1:
         sargv = _set_arg(sargv, "--motion-representation-save-dir", os.path.join(rep_dir, "rank%d" % rank))
         if torch.cuda.is_available():
-            sargv = _set_arg(sargv, "--visible_gpu", local)
+            # the script assigns CUDA_VISIBLE_DEVICES = args.visible_gpu inside main(): hand it the value set above, so
+            # the assignment is a no-op whether or not the runtime is already up
+            sargv = _set_arg(sargv, "--visible_gpu", os.environ["CUDA_VISIBLE_DEVICES"])
+    # Only the latent-condition SparseCtrl (use_simplified_condition_embedding: true, sparsectrl/latent_condition.yaml)
+    # VAE-encodes the condition images and so draws from the global generator (motionclone_functions.py:122-126); the
+    # pixel-condition variant (image_condition.yaml, :127-128) draws nothing for them.
+    encodes_condition = False
+    if is_i2v:
+        encodes_condition = _condition_images_are_encoded(_arg(sargv, ["--inference_config"], "configs/i2v_sketch.yaml"))
 
     def burn(example):
         dev = "cuda" if torch.cuda.is_available() else "cpu"
         torch.randn((L, 4, H // vae_scale, W // vae_scale), device=dev, dtype=torch.float16)
-        n_img = len(example.get("condition_image_paths", ())) if is_i2v else 0
+        n_img = len(example.get("condition_image_paths", ())) if encodes_condition else 0
         if n_img:
             torch.randn((n_img, 4, H // vae_scale, W // vae_scale), device=dev, dtype=torch.float16)
 

@@ -42,7 +42,10 @@ def add_noise(self, timestep, x_0, noise_pred):
 def _sampler(pipe):
     """MotionCloneSampler over the pipeline's unet engine.  Hyper-parameters come from pipe.input_config; the timestep
     table, alphas_cumprod and final_alpha_cumprod are READ FROM pipe.scheduler, as the reference does (:213-214,326-336),
-    so any spacing type / beta schedule / set_alpha_to_one the scheduler was configured with is honoured.  Cached."""
+    so any spacing type / beta schedule / set_alpha_to_one the scheduler was configured with is honoured.  Cached.
+    On the GPU every DDIM step is captured into a hipGraph at its first use and replayed for every later video of the same
+    shape (sampler.enable_graphs; bit-identical to the eager launch sequence, which eta > 0 and MC_NO_GRAPHS=1 still take):
+    the reference API runs the same path bench.py times."""
     c = pipe.input_config
     sch = pipe.scheduler
     ts = tuple(int(t) for t in torch.as_tensor(sch.timesteps).cpu().tolist())
@@ -60,6 +63,8 @@ def _sampler(pipe):
                                               num_inference_steps=c.inference_steps, guidance_steps=c.guidance_steps,
                                               guidance_scale=c.guidance_scale, timesteps=ts, alphas_cumprod=acp,
                                               final_alpha_cumprod=final)
+        if pipe._mc_sampler.dev.type == "cuda" and os.environ.get("MC_NO_GRAPHS", "0") != "1":
+            pipe._mc_sampler.enable_graphs()
         pipe._mc_sampler_key = key
     return pipe._mc_sampler
 

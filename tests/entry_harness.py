@@ -319,7 +319,7 @@ def main():
         L.main([script, "--pretrained-model-path", common["pretrained_model_path"], "--inference_config",
                 common["inference_config"], "--examples", common["examples"], "--motion-representation-save-dir",
                 os.path.join(work, "mr_sharded"), "--generated-videos-save-dir", os.path.join(work, "videos_rank%d" % rank),
-                "--L", str(F), "--W", str(PX), "--H", str(PX), "--vae-scale", "2"])
+                "--L", str(F), "--W", str(px), "--H", str(px), "--vae-scale", "2"])
         print("ENTRY_OK", kind, written)
         return
     ns = runpy.run_path(script, run_name="entry_script_under_test")

@@ -32,8 +32,8 @@ def rel(a, b):
     return ((a - b).norm() / b.norm().clamp_min(1e-12)).item()
 
 
-N_EXAMPLES = {"t2v": 2, "i2v": 1, "i2v_sketch": 1}
-LAST = {"t2v": ("a dog walks 1", 2027), "i2v": ("a cat runs", 42), "i2v_sketch": ("a cat runs", 42)}
+N_EXAMPLES = {"t2v": 2, "i2v": 1, "i2v_sketch": 2}
+LAST = {"t2v": ("a dog walks 1", 2027), "i2v": ("a cat runs", 42), "i2v_sketch": ("a dog walks 1", 2027)}
 
 
 def start_harness(kind, work):
@@ -168,11 +168,14 @@ def test_unmodified_entry_script_matches_oracle(kind, runs):
     assert rel(lp["text"], want_text) < 1e-2
 
 
-def test_launcher_shards_examples_and_reproduces_the_serial_run(runs):
+@pytest.mark.parametrize("kind", ["t2v", "i2v_sketch"])
+def test_launcher_shards_examples_and_reproduces_the_serial_run(runs, kind):
     """motionclone_amd.launch under a 2-rank torchrun environment (gloo): rank r runs the unmodified script on lines
-    r, r+2, ...; with the serial-RNG burn the sharded videos are bit-identical to the single-process run (quirk 10)"""
+    r, r+2, ...; with the serial-RNG burn the sharded videos are bit-identical to the single-process run (quirk 10).
+    i2v_sketch = the pixel-condition SparseCtrl: its condition images are NOT VAE-encoded, so a skipped example burns only
+    the reference video's posterior draw (motionclone_functions.py:122-128)."""
     import socket
-    work, rec = runs("t2v")
+    work, rec = runs(kind)
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
@@ -181,7 +184,7 @@ def test_launcher_shards_examples_and_reproduces_the_serial_run(runs):
     for r in range(2):
         env = dict(os.environ, PYTHONPATH=ROOT, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1",
                    MASTER_PORT=str(port))
-        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), "t2v", str(work),
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), kind, str(work),
                                        "--launch"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env,
                                       cwd=str(work)))
     outs = [p.communicate(timeout=900)[0] for p in procs]
