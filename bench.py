@@ -24,6 +24,7 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+from motionclone_amd.probe import LaunchProbe
 from motionclone_amd import lib, ops, spec  # noqa: E402
 from motionclone_amd.engine import UNet3DEngine, default_config  # noqa: E402
 from motionclone_amd.sampler import MotionCloneSampler, sample_interleaved  # noqa: E402
@@ -31,89 +32,6 @@ from motionclone_amd.sampler import MotionCloneSampler, sample_interleaved  # no
 # algorithmic work of the reference graph, FLOP = 2*MAC (measured on the reference's own code)
 TFLOP_GUIDED, TFLOP_PLAIN, TFLOP_EXTRACT = 45.50, 35.35, 10.06
 PEAK_FP16_MFMA_TFLOPS = 2500.0
-
-
-def gemm_kernel_name(mode, M, N, K=0):
-    """Which kernel instance mc_gemm_f16 picks in auto mode (mirrors the heuristic in csrc/gemm.hip)."""
-    modes = {ops.DENSE: "DENSE", ops.CONV_S1: "CONV_S1", ops.CONV_S2: "CONV_S2", ops.CONV_UP: "CONV_UP",
-             ops.TCONV_S2: "TCONV_S2"}
-    sh = ops._GEMM_SHARE
-    plan = lib.load().mc_gemm_splitk_plan(M, N, K, mode | (sh << 8)) if K else 1
-    if mode == ops.DENSE and K == 320 and N % 32 == 0 and (M >= 98304 or (M >= 32768 and N >= 640)):
-        return "gemm4_kernel<K=320 streaming>"
-    if plan > 1:
-        return "gemm3_kernel<%s,%s> split-K + reduce" % (modes[mode], "256,320,4,2" if (plan >> 8) == 1 else "128,320,2,2")
-    if N % 320 == 0:
-        if ((M + 255) // 256) * (N // 320) >= (224 >> sh):
-            return "gemm3_kernel<%s,256,320,4,2>" % modes[mode]
-        if ((M + 127) // 128) * (N // 320) >= (192 >> sh):
-            return "gemm3_kernel<%s,128,320,2,2>" % modes[mode]
-    if ((M + 127) // 128) * ((N + 127) // 128) < (256 >> sh):
-        return "gemm2_kernel<%s,64,64,2>" % modes[mode]
-    return "gemm2_kernel<%s,128,128,2>" % modes[mode]
-
-
-class GemmProbe:
-    """HIP-event timing of every GEMM / implicit-conv launch inside the timed region, grouped by kernel instance.
-    The kernels are launched on torch's current stream, which is where the events are recorded."""
-
-    def __init__(self):
-        self.events = []
-        self.shapes = []
-        self.enabled = False
-        self._orig = ops.gemm
-
-    def install(self):
-        probe = self
-
-        def gemm(a, w, **kw):
-            if not probe.enabled:
-                return probe._orig(a, w, **kw)
-            mode = kw.get("mode", ops.DENSE)
-            N, K = w.shape
-            M = kw["m_out"] if mode != ops.DENSE else a.shape[0]
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = probe._orig(a, w, **kw)
-            e1.record()
-            n_out = N // 2 if kw.get("geglu") else N
-            # algorithmic bytes: every operand once (activations, weights, residual, output)
-            nbytes = 2.0 * (a.shape[0] * a.shape[1] + (kw["a2"].numel() if kw.get("a2") is not None else 0)
-                            + N * K + M * n_out * (2 if kw.get("residual") is not None else 1))
-            probe.events.append((gemm_kernel_name(mode, M, N, K), e0, e1, 2.0 * M * N * K, nbytes))
-            probe.shapes.append((mode, M, N, K, bool(kw.get("geglu")), kw.get("residual") is not None))
-            return out
-        ops.gemm = gemm
-
-    def by_shape(self):
-        """Per (kernel, shape) totals of the probe video: where the GEMM time goes (tools / DESIGN tables)."""
-        rows = {}
-        for (name, e0, e1, fl, nb), sh in zip(self.events, self.shapes):
-            r = rows.setdefault((name,) + sh, dict(launches=0, ms=0.0, flop=0.0, bytes=0.0))
-            r["launches"] += 1
-            r["ms"] += e0.elapsed_time(e1)
-            r["flop"] += fl
-            r["bytes"] += nb
-        out = []
-        for (name, mode, M, N, K, geglu, res), r in sorted(rows.items(), key=lambda kv: -kv[1]["ms"]):
-            out.append(dict(kernel=name, mode=mode, M=M, N=N, K=K, geglu=geglu, residual=res, launches=r["launches"],
-                            ms=r["ms"], avg_us=1e3 * r["ms"] / r["launches"], tflops=r["flop"] / r["ms"] / 1e9,
-                            alg_gbps=r["bytes"] / r["ms"] / 1e6))
-        return out
-
-    def summary(self):
-        groups = {}
-        for name, e0, e1, fl, nb in self.events:
-            g = groups.setdefault(name, dict(launches=0, ms=0.0, flop=0.0, bytes=0.0))
-            g["launches"] += 1
-            g["ms"] += e0.elapsed_time(e1)
-            g["flop"] += fl
-            g["bytes"] += nb
-        for g in groups.values():
-            g["avg_us"] = 1e3 * g["ms"] / g["launches"]
-            g["tflops"] = g["flop"] / g["ms"] / 1e9
-            g["alg_gbps"] = g["bytes"] / g["ms"] / 1e6
-        return groups
 
 
 def plan_rounds(nvideos, lanes):
@@ -368,8 +286,7 @@ def main():
     # The timed path replays one hipGraph per DDIM step (sampler.enable_graphs: bit-identical to the eager launches,
     # tests/test_fullsize_properties.py); everything that differs between videos enters through static buffers.  The
     # motion-representation extraction (once per video) stays eager.  `--no-graphs` times the eager launch sequence instead.
-    probe = GemmProbe()
-    probe.install()
+    probe = LaunchProbe().install()
     use_graphs = not args.no_graphs
     # Independent (prompt, reference-video) samples are the unit of parallelism of this workload.  `--inflight`
     # of them can run concurrently inside one GPU, each on its own HIP stream with its own sampler (and graphs): the launch
@@ -446,12 +363,17 @@ def main():
         out_e = one_video(sme, lat, text, vid, noise, ctrl=ctrl)
         torch.cuda.synchronize()
         te = time.perf_counter() - te0
+        # the probe video runs with the tile / split-K choice of ONE video in flight (its regime), not the timed region's
+        ops.set_gemm_share(1)
+        one_video(sme, lat, text, vid, noise, ctrl=ctrl)              # the single-lane choice may touch new kernels: warm
+        torch.cuda.synchronize()
         probe.enabled = True
         tp0 = time.perf_counter()
         one_video(sme, lat, text, vid, noise, ctrl=ctrl)
         torch.cuda.synchronize()
         probe_elapsed = time.perf_counter() - tp0
         probe.enabled = False
+        ops.set_gemm_share(args.gemm_lanes or NF)
         eager_info = dict(videos_per_min=60.0 / te, sec_per_video=te, identical_to_graph_path=bool(torch.equal(out_e, out)),
                           note="same launch sequence without hipGraphs, one video; not part of `value`")
         del sme
@@ -469,26 +391,39 @@ def main():
         table = {(16, 256): (10.41, 8.17, 2.39), (16, 512): (45.50, 35.35, 10.06), (32, 768): (235.9, 181.1, 49.7)}
         tg, tp, te = table.get((args.frames, args.size), (float("nan"),) * 3)
         tflop_video = G_STEPS * tg + (N_STEPS - G_STEPS) * tp + te
-        groups = probe.summary()
+        roof_all = probe.summary(probe_elapsed)
+        by_shape = probe.by_shape()
         if args.shapes_out:
-            json.dump(probe.by_shape(), open(args.shapes_out, "w"), indent=1)
-        traffic_tab = {}
-        tfile = os.path.join(ROOT, "profiles", "hbm_traffic_per_launch.json")
-        if os.path.exists(tfile):
-            traffic_tab = json.load(open(tfile))
-        if (args.frames, args.size) != (16, 512):
-            traffic_tab = {}     # the PMC passes were taken at the config-2 shapes only
-        roof, roof_all = None, {}
-        if groups:
-            for name, g in groups.items():
-                roof_all[name] = dict(bound="mfma", achieved=g["tflops"], peak=PEAK_FP16_MFMA_TFLOPS, unit="TFLOP/s",
-                                      frac=g["tflops"] / PEAK_FP16_MFMA_TFLOPS, launches=g["launches"],
-                                      avg_launch_us=g["avg_us"], flop_per_launch=g["flop"] / g["launches"],
-                                      algorithmic_bytes_per_launch=g["bytes"] / g["launches"],
-                                      algorithmic_gbps=g["alg_gbps"], traffic=traffic_tab.get(name),
-                                      share_of_probe_video=(g["ms"] / 1e3 / probe_elapsed))
-            dom = max(groups, key=lambda n: groups[n]["ms"])   # dominant by time inside the timed region
+            json.dump(by_shape, open(args.shapes_out, "w"), indent=1)
+        # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), per SHAPE, next to
+        # that shape's algorithmic bytes; a family's `traffic` is the launch-weighted mean over its measured shapes and
+        # `traffic_vs_algorithmic` the ratio on exactly those shapes
+        traffic_rows = []
+        tfile = os.path.join(ROOT, "profiles", "hbm_traffic_per_shape.json")
+        if os.path.exists(tfile) and (args.frames, args.size) == (16, 512):
+            pmc = json.load(open(tfile))
+            for row in by_shape:
+                for m in pmc:
+                    if m["kernel"] == row["kernel"] and list(m["shape"]) == list(row["shape"]):
+                        traffic_rows.append(dict(kernel=row["kernel"], shape=row["shape"], launches=row["launches"],
+                                                 traffic_bytes_per_launch=m["traffic_bytes"],
+                                                 algorithmic_bytes_per_launch=row["algorithmic_bytes_per_launch"],
+                                                 ratio=m["traffic_bytes"] / row["algorithmic_bytes_per_launch"]))
+            for fam, r in roof_all.items():
+                sel = [t for t in traffic_rows if t["kernel"] == fam]
+                if sel:
+                    n = sum(t["launches"] for t in sel)
+                    r["traffic"] = sum(t["launches"] * t["traffic_bytes_per_launch"] for t in sel) / n
+                    r["traffic_vs_algorithmic"] = r["traffic"] / (sum(t["launches"] * t["algorithmic_bytes_per_launch"] for t in sel) / n)
+                    r["traffic_launch_coverage"] = n / r["launches"]
+        roof = None
+        if roof_all:
+            dom = max(roof_all, key=lambda n: roof_all[n]["share_of_probe_video"])   # dominant by time
             roof = dict(roof_all[dom], kernel=dom)
+        hbm = dict(peak_allocated_gib=torch.cuda.max_memory_allocated(dev) / 2 ** 30,
+                   peak_reserved_gib=torch.cuda.max_memory_reserved(dev) / 2 ** 30, videos_in_flight=NF,
+                   note="torch caching allocator, whole process (weights 2.4 GiB fp16 + packed copies, %d lanes of activations, "
+                        "their hipGraph pools, the eager probe sampler)" % NF)
         res = {
             "metric": "videos/min (%df x %dx%d SD1.5+AnimateDiff-v3 arch, %d-step DDIM, %d guided, MotionClone guidance)"
                       % (args.frames, args.size, args.size, N_STEPS, G_STEPS),
@@ -511,10 +446,16 @@ def main():
             "e2e_tflops_per_gpu": tflop_video * args.steps / elapsed,
             "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
             "roofline": roof,
-            "roofline_note": "per-launch HIP events from ONE eager video run after the timed region (events cannot bracket "
-                             "launches inside a graph replay); `traffic` = PMC HBM bytes per launch of probe shapes "
-                             "(profiles/, tools/pmc_probe.py), null where not collected",
+            "roofline_note": "per-launch HIP events around EVERY C-ABI launch of ONE eager video run after the timed region "
+                             "(events cannot bracket launches inside a graph replay), tile choice of one video in flight; each row's "
+                             "`bound` is the roof it is closer to (dense fp16 MFMA 2.5 PF vs HBM 8 TB/s, algorithmic flop / bytes); "
+                             "`traffic` = PMC HBM bytes per launch on the shapes listed in roofline_traffic_by_shape (profiles/), null "
+                             "where not collected; per-kernel durations of the TIMED regime (graphs, videos in flight): rocprofv3 "
+                             "trace in profiles/r03_kernel_stats.md",
             "roofline_by_kernel": roof_all,
+            "roofline_coverage_of_probe_video": probe.covered(probe_elapsed),
+            "roofline_traffic_by_shape": traffic_rows,
+            "hbm_footprint": hbm,
             # SURVEY.md 8(f) rank 1, measured OUTSIDE the timed region (BASELINE's metric is the UNet loop): the VAE calls
             # around it - decode_latents of the sampled video and the encode of the reference video - on the same kernels
             "vae": vae_info,

@@ -67,6 +67,10 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
 /* PROFILING ONLY: timing experiments that drop parts of the GEMM kernels (1 = no global stores, 2 = no MFMA loop,
  * 4 = no epilogue, 8 = no operand staging); outputs are garbage while set.  0 restores normal operation. */
 int mc_gemm_debug(int bits);
+/* PROFILING ONLY: the kernel structure used by the calling thread's last mc_gemm_f16 / mc_gemm_splitk_f16 call:
+ * 2 / 20 = gemm2 128x128 / 64x64 tiles, 31..35 = gemm3 geometry 1..5, 4 = gemm4, 51 / 54 = gemm5 with 256- / 128-row tiles;
+ * + 100 for a split-K call (bench.py names its roofline rows with it). */
+int mc_gemm_last_kernel(void);
 int mc_tattn_debug_buffer(void* device_buffer); /* tools only: intermediates of mc_tattn_bwd_f16 (F <= 16, d = 40), units*64*24 floats */
 int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
 

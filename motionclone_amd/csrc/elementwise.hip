@@ -455,7 +455,10 @@ extern "C" int mc_version(void) { return 1; }
 
 // ---- workspace sizes (bytes) of the entry points that take a caller-owned workspace -----------------------------------
 extern "C" long mc_workspace_bytes_gemm_splitk(int M, int N, int splits) {
-    return (M <= 0 || N <= 0 || splits < 1) ? -1 : (long)sizeof(float) * splits * M * N;
+    // fp32 partial sums of `splits` K ranges over whole tiles (256 x 320: the slabs of gemm5 are tile-shaped)
+    if (M <= 0 || N <= 0 || splits < 1) return -1;
+    const long mp = ((long)M + 255) / 256 * 256, np = ((long)N + 319) / 320 * 320;
+    return (long)sizeof(float) * splits * mp * np;
 }
 extern "C" long mc_workspace_bytes_attn_bwd(int nbatch, int heads, int Nq) {
     return (nbatch <= 0 || heads <= 0 || Nq <= 0) ? -1 : (long)sizeof(float) * nbatch * heads * Nq;

@@ -27,27 +27,112 @@
 namespace mc {
 
 namespace g5 {
-constexpr int BM = 256, BN = 320, NW = 8, NT = 512, TM = 2, TN = 5, BKT = 32, NS = 4;
+constexpr int BN = 320, NW = 8, NT = 512, TN = 5, BKT = 32, NS = 4;
 constexpr int ROWB = 64;                 // bytes per staged row (32 halfs)
 constexpr int RPI = 16;                  // rows moved by one LDS-DMA instruction
-constexpr int STAGE = (BM + BN) * ROWB;  // 36864
-constexpr int A_BYTES = BM * ROWB;
-constexpr int LA = 5, LB = 4;            // LDS-DMA instructions per stage: waves 0-3 (2 A + 3 W) / waves 4-7 (2 A + 2 W)
 constexpr int RS = 336;                  // row pitch of the epilogue's fp16 image (bytes)
 constexpr int RSG = 176;                 // same, fused GEGLU (80 outputs per row)
-constexpr int STG = 32 * RS;             // one 32-row half of a wave's tile
-constexpr size_t SMEM = (size_t)NS * STAGE;
-static_assert(NW * STG <= NS * STAGE, "epilogue image must fit the ring");
+constexpr int STG = 32 * RS;             // one 32-row block of a wave's tile
+// BM = 256: wave tile 64 x 160 (two 32-row blocks); BM = 128: 32 x 160 - same 8 waves, for problems that do not fill the
+// 256 CUs with 256-row tiles (the 16x16 / 8x8 levels); more LDS and L2 traffic per MFMA, still two waves per SIMD
+template <int BM>
+struct Tile {
+    static constexpr int TM = BM / 128;
+    static constexpr int RA = BM / RPI / NW;             // activation row groups per wave and stage
+    static constexpr int STAGE = (BM + BN) * ROWB;       // 36864 / 28672
+    static constexpr int A_BYTES = BM * ROWB;
+    static constexpr int LB = RA + 2, LA = RA + 3;       // LDS-DMA instructions per stage: waves 4-7 / waves 0-3 (one more weight group)
+    static constexpr size_t SMEM = (size_t)NS * STAGE;
+    static_assert(BM % 128 == 0 && NW * STG <= NS * STAGE, "epilogue image must fit the ring");
+};
 
 __device__ __forceinline__ int lds_off32(int row, int v) { return row * 64 + ((v ^ ((row >> 2) & 3)) << 4); }
 }  // namespace g5
 
-// VAR (timing experiments, tools/gemm5_bench.py): bit 0 = no stagger (every wave issues its loads in the first half),
-// bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
-template <int MODE, int EPI, int VAR>
+// Wave-private epilogue of one wave tile (32 TM rows x 160 columns at global (mw0, nw0)): bias / alpha in fp32 in the
+// accumulator layout, fp16 through the wave's LDS image `stg` (32 rows, pitch 336 B), read back as whole 320-byte row segments
+// and stored 16 bytes per lane with the residual added on the way.  No workgroup barrier.
+template <int EPI, int TM>
+__device__ __forceinline__ void g5_epilogue(const GemmParams& p, f32x16 (&acc)[g5::TN][TM], char* stg, int mw0, int nw0, int lane) {
+    using namespace g5;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    constexpr int SEGS = EPI == 1 ? 10 : 20;          // 16-byte segments per image row
+    constexpr int PITCH = EPI == 1 ? RSG : RS;
+    constexpr int RPI_OUT = 60 / SEGS;                // rows per read-back instruction (60 of 64 lanes)
+    constexpr int NIT = (32 + RPI_OUT - 1) / RPI_OUT;
+    const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == RPI_OUT -> idle
+    const int ncol = EPI == 1 ? nw0 / 2 + seg * 8 : nw0 + seg * 8;   // first output column of the lane's segment
+    const int nout = EPI == 1 ? p.N / 2 : p.N;
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int mrow = mw0 + 32 * j;                // global row of image row 0
+        // residual rows of this half: in flight while the accumulators are converted and transposed
+        half8_t rres[NIT];
+        if (EPI == 0 && p.R) {
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int r = it * RPI_OUT + rsel, m = mrow + r;
+                if (rsel < RPI_OUT && r < 32 && m < p.M && ncol < nout) rres[it] = ld8(p.R + (size_t)m * p.ldr + ncol);
+            }
+        }
+        // accumulators (lane: row l31, 4 consecutive columns per (i, q)) -> + bias, * alpha -> fp16 image
+        const int mlane = mrow + l31;
+        const float* brow = p.bias ? p.bias + (size_t)(min(mlane, p.M - 1) / p.rows_per_batch) * p.N : nullptr;
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int cl = 32 * i + 8 * q + 4 * lhi;   // column within the wave's 160
+                const int n = nw0 + cl;
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
+                if (brow && n < p.N) {
+                    f32x4 b = *reinterpret_cast<const f32x4*>(brow + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                }
+                if (EPI == 1) {   // fused GEGLU: columns are (h, gate) pairs
+                    half2_t o;
+                    o[0] = to_half(v[0] * gelu_f(v[1]));
+                    o[1] = to_half(v[2] * gelu_f(v[3]));
+                    *reinterpret_cast<half2_t*>(stg + l31 * PITCH + cl) = o;
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + cl * 2) = o;
+                }
+            }
+        }
+        wave_lds_sync();
+        // image rows -> global: 16 bytes per lane, whole row segments of the wave's columns
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel, m = mrow + r;
+            if (rsel < RPI_OUT && r < 32 && m < p.M && ncol < nout) {
+                half8_t o = *reinterpret_cast<const half8_t*>(stg + r * PITCH + seg * 16);
+                if (EPI == 0 && p.R) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half((float)o[e] + (float)rres[it][e]);
+                }
+                st8(p.C + (size_t)m * p.ldc + ncol, o);
+            }
+        }
+        wave_lds_sync();   // the image is rewritten by the next half
+    }
+}
+
+
+// VAR (timing experiments, tools/gemm5_bench.py): bit 0 = STAGGER the LDS-DMA issue between the two waves of a SIMD (waves 0-3
+// in the first half of a stage, waves 4-7 in the second; measured 1-8 % slower than everybody in the first half, which is the
+// default), bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
+template <int MODE, int EPI, int VAR, int BM>
 __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2, uint32_t bytesW,
                                                         int tilesM, int tilesN) {
     using namespace g5;
+    using T = Tile<BM>;
+    constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB;
     MC_DYN_SMEM(smem);
 
     const int tid = threadIdx.x;
@@ -79,9 +164,9 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     const int rsub = lane >> 2;
     const int lslot = (lane & 3) ^ (lane >> 4);
 
-    int a_valid[2], a_pix[2], a_oy[2], a_ox[2];
+    int a_valid[RA], a_pix[RA], a_oy[RA], a_ox[RA];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < RA; ++i) {
         int m = m0 + (wave + NW * i) * RPI + rsub;
         a_valid[i] = m < p.M;
         if (MODE == DENSE) {
@@ -105,10 +190,10 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
         w_off[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)lslot * 16u : kOOB;
     }
 
-    // one LDS-DMA instruction of stage tile kt: piece 0,1 = activation row groups, 2,3,4 = weight row groups
+    // one LDS-DMA instruction of stage tile kt: pieces 0 .. RA-1 = activation row groups, then 2 (3) weight row groups
     auto issue_piece = [&](int kt, int buf, int piece) {
         char* base = smem + buf * STAGE;
-        if (piece < 2) {
+        if (piece < RA) {
             const int i = piece;
             int tap = 0, c0 = kt * BKT;
             if (MODE != DENSE) {   // K order: 64-channel tile major, tap minor; a stage is half a 64-channel tile
@@ -157,15 +242,15 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
             else
                 glds16(bufA, voff, dst);
         } else {
-            const int i = piece - 2;
+            const int i = piece - RA;
             uint32_t voff = w_off[i] + (uint32_t)kt * (BKT * 2u);   // kOOB + a small offset stays out of range
             glds16(bufW, voff, base + A_BYTES + (i < 2 ? wave + NW * i : 16 + (wave & 3)) * 1024);
         }
     };
     auto issue_stage = [&](int kt, int buf) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) issue_piece(kt, buf, q);
-        if (grpA) issue_piece(kt, buf, 4);
+        for (int q = 0; q < LB; ++q) issue_piece(kt, buf, q);
+        if (grpA) issue_piece(kt, buf, LB);
     };
     // wait until at most `tiles` (0..2) of this wave's staged tiles are still in flight (loads retire in order)
     auto wait_tiles = [&](int tiles) {
@@ -187,7 +272,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wr = wave & 3, wc = wave >> 2;
-    const int wm0 = wr * 64, wn0 = wc * 160;
+    const int wm0 = wr * (32 * TM), wn0 = wc * 160;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     const int split = blockIdx.y;
@@ -196,7 +281,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     const int nk = (int)((long)(split + 1) * nk_all / p.splits);
 
     // prologue: waves 0-3 put stages 0..2 in flight, waves 4-7 stages 0..3 (they issue stage j + 4 in the second half of j)
-    const bool stagger = !(VAR & 1);
+    const bool stagger = (VAR & 1) != 0;
     const int nst = nk - kt_begin;
 #pragma unroll
     for (int s0 = 0; s0 < 3; ++s0)
@@ -214,14 +299,15 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
         for (int i = 0; i < TN; ++i)
             w[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * ks + lhi));
     };
-    // Half a stage = one scheduling region: the 10 MFMAs of the current k-slice (`ca / cw`), the 7 fragment reads of the
-    // NEXT one (into `ra / rw`) and NL LDS-DMA instructions of stage `lkt` (ring slot `lbuf`), in this order:
-    //   read a'0, a'1;  then for each weight fragment i:  MFMA (i,0), MFMA (i,1), read w'i, [one LDS-DMA]
-    // A weight fragment is dead after its two MFMAs, so w'i can take its registers: 5 + 2 x 2 fragments live instead of
-    // 2 x 7 (the 256-register budget holds 160 accumulators), and no instruction kind is issued in a burst.
+    // Half a stage = one scheduling region: the 5 TM MFMAs of the current k-slice (`ca / cw`), the TM + 5 fragment reads of
+    // the NEXT one (into `ra / rw`) and NL LDS-DMA instructions of stage `lkt` (ring slot `lbuf`), in this order:
+    //   read a'0 [, a'1];  then for each weight fragment i:  MFMA (i,0) [, (i,1)], read w'i, [one LDS-DMA]
+    // A weight fragment is dead after its MFMAs, so w'i can take its registers: 5 + 2 TM fragments live instead of
+    // 2 x (5 + TM) (the 256-register budget holds 160 accumulators at TM = 2), and no instruction kind is issued in a burst.
     auto half_step = [&](auto nl_tag, int rbuf, int rks, half8_t* ra, half8_t* rw, const half8_t* ca, const half8_t* cw,
                          int lkt, int lbuf) {
         constexpr int NL = decltype(nl_tag)::value;
+        static_assert(NL <= TN, "one LDS-DMA behind each weight fragment at most");
         const char* bA = smem + rbuf * STAGE;
         const char* bW = bA + A_BYTES;
 #pragma unroll
@@ -235,19 +321,19 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
             if (i < NL) issue_piece(lkt, lbuf, i);
         }
 #ifndef MC_EMU
-        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);          // DS read: a'0, a'1
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);          // DS read: a'0 [, a'1]
         if (NL > 0 && (VAR & 2)) __builtin_amdgcn_sched_group_barrier(0x010, NL, 0);   // experiment: LDS-DMA burst at the top
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
-            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);      // MFMA (i, 0), (i, 1)
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);      // MFMA (i, 0) [, (i, 1)]
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // DS read w'i
             if (!(VAR & 2) && i < NL) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);   // one LDS-DMA
         }
 #endif
     };
     using N0 = std::integral_constant<int, 0>;
-    using N4 = std::integral_constant<int, 4>;
-    using N5 = std::integral_constant<int, 5>;
+    using NLB = std::integral_constant<int, LB>;
+    using NLA = std::integral_constant<int, LA>;
 
     // stage 0 landed: this wave's own loads (counted: waves 4-7 may have three younger stages in flight), then everybody's
     {
@@ -264,7 +350,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
         // steady state of waves 0-3: stage kt + 3 goes into the slot freed at the previous barrier
         for (; kt + 3 < nk; ++kt) {
             const int nbuf = (buf + 1) & 3;
-            half_step(N5(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
+            half_step(NLA(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
             // stage kt + 1 landed (own loads: counted wait, two younger stages stay in flight; everybody's: barrier).  Past
             // the barrier every wave has also finished reading stage kt (slice-1 fragments are in registers)
             wait_vmcnt_le<2 * LA>();
@@ -273,23 +359,23 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
             buf = nbuf;
         }
     } else if (!stagger) {
-        // experiment (VAR bit 0): waves 4-7 issue in the first half like waves 0-3
+        // waves 4-7: the same with one weight row group less
         for (; kt + 3 < nk; ++kt) {
             const int nbuf = (buf + 1) & 3;
-            half_step(N4(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
+            half_step(NLB(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
             wait_vmcnt_le<2 * LB>();
             raw_barrier();
             half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
             buf = nbuf;
         }
     } else {
-        // steady state of waves 4-7: stage kt + 4 goes into slot `buf` right after the barrier that frees it
+        // experiment (VAR bit 0): waves 4-7 issue stage kt + 4 into slot `buf` right after the barrier that frees it
         for (; kt + 4 < nk; ++kt) {
             const int nbuf = (buf + 1) & 3;
             half_step(N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
             wait_vmcnt_le<2 * LB>();
             raw_barrier();
-            half_step(N4(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + 4, buf);
+            half_step(NLB(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + 4, buf);
             buf = nbuf;
         }
     }
@@ -304,106 +390,106 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     }
     // every wave passed the last barrier after its final LDS read and no load is in flight: the ring is free
 
-    // ---- epilogue: wave-private, two 32-row halves ----
-    char* stg = smem + wave * STG;
-    constexpr int SEGS = EPI == 1 ? 10 : 20;          // 16-byte segments per image row
-    constexpr int PITCH = EPI == 1 ? RSG : RS;
-    constexpr int RPI_OUT = 60 / SEGS;                // rows per read-back instruction (60 of 64 lanes)
-    constexpr int NIT = (32 + RPI_OUT - 1) / RPI_OUT;
-    const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == RPI_OUT -> idle
-    const int ncol = EPI == 1 ? (n0 + wn0) / 2 + seg * 8 : n0 + wn0 + seg * 8;   // first output column of the lane's segment
-    const int nout = EPI == 1 ? p.N / 2 : p.N;
+    if (p.ws) {
+        // split-K: this workgroup's partial sums go to its slab in ACCUMULATOR-NATIVE order - chunk (i, j, q) of lane l at
+        // float4 index ((i TM + j) 4 + q) 64 + l - so every store instruction writes 1 KiB contiguously; splitk_reduce5_kernel
+        // sums the slabs in split order and runs the epilogue below
+        float* slab = p.ws + ((((size_t)split * tilesM * tilesN + (size_t)tm * tilesN + tn) * NW + wave) * (size_t)(TN * TM * 16 * 64));
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-        const int mrow = m0 + wm0 + 32 * j;           // global row of image row 0
-        // residual rows of this half: in flight while the accumulators are converted and transposed
-        half8_t rres[NIT];
-        if (EPI == 0 && p.R) {
+        for (int i = 0; i < TN; ++i)
 #pragma unroll
-            for (int it = 0; it < NIT; ++it) {
-                const int r = it * RPI_OUT + rsel, m = mrow + r;
-                if (rsel < RPI_OUT && r < 32 && m < p.M && ncol < nout) rres[it] = ld8(p.R + (size_t)m * p.ldr + ncol);
-            }
-        }
-        // accumulators (lane: row l31, 4 consecutive columns per (i, q)) -> + bias, * alpha -> fp16 image
-        const int mlane = mrow + l31;
-        const float* brow = p.bias ? p.bias + (size_t)(min(mlane, p.M - 1) / p.rows_per_batch) * p.N : nullptr;
+            for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int cl = 32 * i + 8 * q + 4 * lhi;   // column within the wave's 160
-                const int n = n0 + wn0 + cl;
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * p.alpha;
-                if (brow && n < p.N) {
-                    f32x4 b = *reinterpret_cast<const f32x4*>(brow + n);
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += b[e];
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e];
+                    *reinterpret_cast<f32x4*>(slab + (((i * TM + j) * 4 + q) * 64 + lane) * 4) = v;
                 }
-                if (EPI == 1) {   // fused GEGLU: columns are (h, gate) pairs
-                    half2_t o;
-                    o[0] = to_half(v[0] * gelu_f(v[1]));
-                    o[1] = to_half(v[2] * gelu_f(v[3]));
-                    *reinterpret_cast<half2_t*>(stg + l31 * PITCH + cl) = o;
-                } else {
-                    half4_t o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
-                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + cl * 2) = o;
-                }
-            }
-        }
-        wave_lds_sync();
-        // image rows -> global: 16 bytes per lane, whole row segments of the wave's columns
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int r = it * RPI_OUT + rsel, m = mrow + r;
-            if (rsel < RPI_OUT && r < 32 && m < p.M && ncol < nout) {
-                half8_t o = *reinterpret_cast<const half8_t*>(stg + r * PITCH + seg * 16);
-                if (EPI == 0 && p.R) {
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) o[e] = to_half((float)o[e] + (float)rres[it][e]);
-                }
-                st8(p.C + (size_t)m * p.ldc + ncol, o);
-            }
-        }
-        wave_lds_sync();   // the image is rewritten by the next half
+        return;
     }
+    g5_epilogue<EPI, TM>(p, acc, smem + wave * STG, m0 + wm0, n0 + wn0, lane);
 }
 
-template <int MODE, int EPI, int VAR>
+// Split-K second pass: one wave per wave tile.  Sums the `splits` slabs of its wave tile in split order (deterministic),
+// then runs the same epilogue as the one-pass kernel.  grid = tiles * 8 single-wave workgroups: the reduction uses the
+// whole chip's bandwidth however few tiles the problem has.
+template <int TM>
+__global__ __launch_bounds__(64) void splitk_reduce5_kernel(GemmParams p, int tilesM, int tilesN) {
+    using namespace g5;
+    MC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63;
+    const int tile = blockIdx.x / NW, wave = blockIdx.x % NW;
+    const int tm = tile / tilesN, tn = tile - tm * tilesN;
+    const int wr = wave & 3, wc = wave >> 2;
+    constexpr int CH = TN * TM * 4;                              // float4 chunks per lane
+    const size_t slab_floats = (size_t)CH * 64 * 4;
+    const size_t split_stride = (size_t)tilesM * tilesN * NW * slab_floats;
+    const float* base = p.ws + ((size_t)tile * NW + wave) * slab_floats + (size_t)lane * 4;
+    f32x16 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    for (int s = 0; s < p.splits; ++s) {
+        const float* src = base + (size_t)s * split_stride;
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    f32x4 v = *reinterpret_cast<const f32x4*>(src + (size_t)(((i * TM + j) * 4 + q) * 64) * 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[i][j][4 * q + e] += v[e];
+                }
+    }
+    g5_epilogue<0, TM>(p, acc, smem, tm * (128 * TM) + wr * (32 * TM), tn * BN + wc * 160, lane);
+}
+
+template <int MODE, int EPI, int VAR, int BM>
 static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
-    int tM = (p.M + g5::BM - 1) / g5::BM, tN = (p.N + g5::BN - 1) / g5::BN;
-    allow_big_smem(gemm5_kernel<MODE, EPI, VAR>, g5::SMEM);
+    using T = g5::Tile<BM>;
+    int tM = (p.M + BM - 1) / BM, tN = (p.N + g5::BN - 1) / g5::BN;
+    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM>, T::SMEM);
     dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN), (unsigned)p.splits);
-    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR>), grid, dim3(g5::NT), g5::SMEM, stream, p, bA, bA2, bW, tM, tN);
-    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM>), grid, dim3(g5::NT), T::SMEM, stream, p, bA, bA2, bW, tM, tN);
+    if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
+    if (p.ws) {
+        MC_LAUNCH((splitk_reduce5_kernel<T::TM>), dim3((unsigned)(tM * tN * g5::NW)), dim3(64), (size_t)g5::STG, stream, p, tM, tN);
+        if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
+    }
+    return MC_OK;
 }
 
+// var: 0 = shipped schedule, 256-row tiles; 1 / 2 / 3 = schedule experiments (dense and stride-1 conv); 4 = 128-row tiles
 template <int MODE>
 static int launch5_var(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, int var, hipStream_t s) {
     if (p.epi == 1) {
         if (MODE != DENSE) return MC_ERR_UNSUPPORTED;
-        return launch5<DENSE, 1, 0>(p, bA, bA2, bW, s);
+        return var == 4 ? launch5<DENSE, 1, 0, 128>(p, bA, bA2, bW, s) : launch5<DENSE, 1, 0, 256>(p, bA, bA2, bW, s);
     }
-    if (var == 0) return launch5<MODE, 0, 0>(p, bA, bA2, bW, s);
+    if (var == 0) return launch5<MODE, 0, 0, 256>(p, bA, bA2, bW, s);
+    if (var == 4) return launch5<MODE, 0, 0, 128>(p, bA, bA2, bW, s);
     if constexpr (MODE == DENSE || MODE == CONV_S1) {   // schedule experiments (tools/gemm5_bench.py)
-        if (var == 1) return launch5<MODE, 0, 1>(p, bA, bA2, bW, s);
-        if (var == 2) return launch5<MODE, 0, 2>(p, bA, bA2, bW, s);
-        if (var == 3) return launch5<MODE, 0, 3>(p, bA, bA2, bW, s);
+        if (var == 1) return launch5<MODE, 0, 1, 256>(p, bA, bA2, bW, s);
+        if (var == 2) return launch5<MODE, 0, 2, 256>(p, bA, bA2, bW, s);
+        if (var == 3) return launch5<MODE, 0, 3, 256>(p, bA, bA2, bW, s);
     }
     return MC_ERR_UNSUPPORTED;
 }
 
-// Returns MC_ERR_UNSUPPORTED for what stays on gemm3: split-K, N / ldc / ldr not multiples of 8, operands >= 2 GiB.
+// Returns MC_ERR_UNSUPPORTED for what stays on gemm3: N / ldc / ldr not multiples of 8, operands >= 2 GiB.
+// Split-K (p.ws != null, p.splits > 1): workspace of mc_workspace_bytes_gemm_splitk bytes, var 0 (256-row) or 4 (128-row tiles).
 int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStream_t stream) {
     size_t bytesA = (rowsA * (size_t)p.lda) * 2, bytesA2 = p.A2 ? (rowsA * (size_t)p.lda2) * 2 : 0;
     size_t bytesW = (size_t)p.N * p.K * 2;
     const size_t lim = 0x7FFFFFF0u;
     if (bytesA > lim || bytesA2 > lim || bytesW > lim) return MC_ERR_UNSUPPORTED;
-    if (p.ws || p.splits != 1) return MC_ERR_UNSUPPORTED;
+    if ((p.ws != nullptr) != (p.splits > 1)) return MC_ERR_UNSUPPORTED;
+    if (p.ws && (p.epi == 1 || (var != 0 && var != 4))) return MC_ERR_UNSUPPORTED;
     if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
     if (p.epi == 1 && (p.N & 15)) return MC_ERR_UNSUPPORTED;
     switch (mode) {

@@ -36,11 +36,23 @@ extern "C" int mc_gemm_debug_buffer(void* buf) {   // device buffer for in-kerne
 // +1 % for share 2; with one video in flight share 1 costs 5 %).
 static inline long fill_of(long full, int share) { return full >> share; }
 
+// PROFILING ONLY (bench.py / motionclone_amd/probe.py): which kernel structure the calling thread's last mc_gemm_f16 /
+// mc_gemm_splitk_f16 call used - 2 / 20 = gemm2 128x128 / 64x64, 31..35 = gemm3 geometry 1..5, 4 = gemm4, 51 / 54 = gemm5 with
+// 256- / 128-row tiles; + 100 for a split-K call.  Lets the roofline table name kernels without restating the choice below.
+static thread_local int g_last_kernel = 0;
+extern "C" int mc_gemm_last_kernel(void) { return g_last_kernel; }
+
 static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int nsplit, int share, hipStream_t s) {
     const int M = p.M, N = p.N;
     const size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (p.Ho * p.Wo)) * p.Hs * p.Ws;
-    if (big_cfg == 10) return mode == DENSE ? gemm4_dispatch(p, nsplit, s) : MC_ERR_UNSUPPORTED;
-    if (big_cfg >= 11) return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);   // 11 = the shipped schedule, 12.. = experiments
+    if (big_cfg == 10) {
+        g_last_kernel = 4;
+        return mode == DENSE ? gemm4_dispatch(p, nsplit, s) : MC_ERR_UNSUPPORTED;
+    }
+    if (big_cfg >= 11) {   // 11 = gemm5, 12-14 = schedule experiments, 15 = 128-row tiles
+        g_last_kernel = big_cfg == 15 ? 54 : 51;
+        return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);
+    }
     static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
     static const int g5_var = getenv("MC_GEMM5_VAR") ? atoi(getenv("MC_GEMM5_VAR")) : 0;   // A/B only
     const bool automatic = !big_cfg && !tile && !deep;   // an explicit cfg = 1 still means gemm3 (tests, A/B tools)
@@ -51,6 +63,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         static const int no_g4 = getenv("MC_NO_GEMM4") ? atoi(getenv("MC_NO_GEMM4")) : 0;   // diagnosis only
         if (!no_g4 && mode == DENSE && p.K == 320 && !p.A2 && (M >= 98304 || (M >= 32768 && N >= 640))) {
             int rc4 = gemm4_dispatch(p, 0, s);
+            g_last_kernel = 4;
             if (rc4 != MC_ERR_UNSUPPORTED) return rc4;
         }
         if (N % 320 == 0) {
@@ -61,10 +74,17 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     }
     if (big_cfg == 1 && automatic && !no_g5) {
         int rc5 = gemm5_dispatch(p, mode, (mode == DENSE || mode == CONV_S1) && !p.epi ? g5_var : 0, rowsA, s);
+        g_last_kernel = 51;
+        if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
+    }
+    if (big_cfg == 4 && automatic && !no_g5) {   // 128-row tiles with 8 waves instead of gemm3's 4-wave 128x320 geometry
+        int rc5 = gemm5_dispatch(p, mode, 4, rowsA, s);
+        g_last_kernel = 54;
         if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
     }
     if (big_cfg) {
         int rc3 = gemm3_dispatch(p, mode, big_cfg, rowsA, s);
+        g_last_kernel = 30 + big_cfg;
         if (rc3 != MC_ERR_UNSUPPORTED) return rc3;
     }
     int small_tile = tile == 64;
@@ -72,6 +92,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         long big = (long)((M + 127) / 128) * ((N + 127) / 128);
         small_tile = big < fill_of(256, share);
     }
+    g_last_kernel = small_tile ? 20 : 2;
     return gemm2_dispatch(p, mode, small_tile, deep, rowsA, s);
 }
 
@@ -253,6 +274,16 @@ extern "C" int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, 
     p.s2_pad = (flags & 0x800) ? 0 : 1;
     hipStream_t s = (hipStream_t)stream;
     size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
+    // gemm5 (ring kernel, 256- or 128-row tiles): partial sums in accumulator-native slabs + its own reduce / epilogue pass
+    static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
+    if (!no_g5 && splits > 1 && (cfg == 1 || cfg == 4) && !(flags & 0x1000000)) {
+        GemmParams q = p;
+        q.R = (const half_t*)R; q.bias = bias;
+        int rc5 = gemm5_dispatch(q, mode, cfg == 4 ? 4 : 0, rowsA, s);
+        g_last_kernel = cfg == 4 ? 154 : 151;
+        if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
+    }
+    g_last_kernel = 130 + cfg;
     int rc = gemm3_dispatch(p, mode, cfg, rowsA, s);
     if (rc != MC_OK) return rc;
     long nthr = (long)M * (N / 4);

@@ -95,13 +95,14 @@ def set_gemm_share(lanes):
 
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
          rows_per_batch=0, tile=0, m_out=None, geglu=False, deep=False, cfg=0, splits=None,
-         pad_front=True, nsplit=0):
+         pad_front=True, nsplit=0, g3_splitk=False):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
 
     geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
     geglu=True: w rows interleaved (h_j, gate_j) (see `interleave_geglu`), out gets N/2 columns h*gelu(gate).
     splits: K ranges for the split-K path (None = the library's plan, 1 = off).
-    pad_front=False (CONV_S2 only): zero padding only right / bottom, i.e. F.pad(x, (0, 1, 0, 1)) + stride-2 conv."""
+    pad_front=False (CONV_S2 only): zero padding only right / bottom, i.e. F.pad(x, (0, 1, 0, 1)) + stride-2 conv.
+    g3_splitk (A/B tools): keep the split-K path on the round-2 kernels (gemm3 + splitk_reduce)."""
     _f16(a), _f16(w)
     N, K = w.shape
     c1 = a.shape[1]
@@ -119,7 +120,7 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
     flags = tile | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
-        | (0 if pad_front else 0x800) | (nsplit << 16) | (_GEMM_SHARE << 20)
+        | (0 if pad_front else 0x800) | (nsplit << 16) | (_GEMM_SHARE << 20) | (0x1000000 if g3_splitk else 0)
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N

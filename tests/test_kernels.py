@@ -84,10 +84,11 @@ def test_gemm_large_tile_geometries(backend, cfg):
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm3 geglu")
 
 
-@pytest.mark.parametrize("var", [0, 1, 2, 3])
+@pytest.mark.parametrize("var", [0, 1, 2, 3, 4])
 def test_gemm5_ring_kernel(backend, var):
     """gemm5.hip (4-stage ring, staggered LDS-DMA, wave-private epilogue), forced with cfg = 11 + schedule variant: dense with
-    per-batch bias / residual / alpha / M and N tails / short and long K (2 .. 40 ring stages), two-source conv, fused GEGLU"""
+    per-batch bias / residual / alpha / M and N tails / short and long K (2 .. 40 ring stages), two-source conv, fused GEGLU;
+    var 4 = the 128-row tile geometry"""
     dev = backend
     cfg = 11 + var
     for (M, N, K) in ([(300, 328, 64), (260, 640, 192)] if not big(dev) else [(3000, 968, 128), (5000, 640, 1280)]):
@@ -100,8 +101,8 @@ def test_gemm5_ring_kernel(backend, var):
         close(out, lin + res.float(), 2e-2, 5e-3, "gemm5 dense %d %d %d" % (M, N, K))
         out2 = ops.gemm(a, w, cfg=cfg)
         close(out2, a.float() @ w.float().t(), 2e-2, 5e-3, "gemm5 dense plain")
-    if var:
-        return   # the schedule variants exist for the dense and stride-1 conv kernels only
+    if var in (1, 2, 3):
+        return   # the schedule experiments exist for the dense and stride-1 conv kernels only
     NF, Cin, Cout, H, W = (2, 64, 72, 6, 10) if not big(dev) else (4, 128, 320, 24, 20)
     x, x2 = rnd((NF, Cin, H, W), dev, 5), rnd((NF, 64, H, W), dev, 6)
     wc = rnd((Cout, Cin + 64, 3, 3), dev, 7, 0.05)

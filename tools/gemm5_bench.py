@@ -4,8 +4,9 @@
 
   python tools/gemm5_bench.py [--rounds 5] [--iters 10] [--variants 1,11,12,13,14] [--only conv]
 
-variant numbers = mc_gemm_f16 flags bits 12-15: 1 = gemm3 256x320, 10 = gemm4 (K = 320 only), 11 = gemm5, 12/13/14 = gemm5 without
-stagger / with the LDS-DMA burst at the top / both."""
+variant numbers = mc_gemm_f16 flags bits 12-15: 0 = the library's own choice (incl. split-K), 1 = gemm3 256x320, 4 = gemm3 128x320
+(4 waves), 10 = gemm4 (K = 320 only), 11 = gemm5, 12/13/14 = gemm5 with stagger / with the LDS-DMA burst at the top / both,
+15 = gemm5 with 128-row tiles."""
 import argparse
 import json
 import statistics
@@ -46,6 +47,19 @@ SHAPES = [
     ("conv_l2 1280->1280 +R", 1, F2 * 256, 1280, 11520, True, False, (16, 16, 16, 16)),
     ("conv_up l1->l0 640", 3, F2 * 4096, 640, 5760, False, False, (32, 32, 64, 64)),
     ("conv_down l0->l1 320", 2, F2 * 1024, 320, 2880, False, False, (64, 64, 32, 32)),
+    # the 16x16 (M = 8192 at B = 2, 4096 in the backward) and 8x8 (2048 / 1024) levels: few tiles, deep K
+    ("small conv_l2 2560->1280 +R", 1, F2 * 256, 1280, 23040, True, False, (16, 16, 16, 16)),
+    ("small conv_l2 bwd 1280->1280", 1, 16 * 256, 1280, 11520, False, False, (16, 16, 16, 16)),
+    ("small conv_l3 1280->1280 +R", 1, F2 * 64, 1280, 11520, True, False, (8, 8, 8, 8)),
+    ("small conv_l3 2560->1280 +R", 1, F2 * 64, 1280, 23040, True, False, (8, 8, 8, 8)),
+    ("small conv_l3 bwd 1280->1280", 1, 16 * 64, 1280, 11520, False, False, (8, 8, 8, 8)),
+    ("small qkv_l3", 0, 2048, 3840, 1280, False, False, None),
+    ("small proj_l3 +R", 0, 2048, 1280, 1280, True, False, None),
+    ("small ff1_l3 geglu", 0, 2048, 10240, 1280, False, True, None),
+    ("small ff2_l3 +R", 0, 2048, 1280, 5120, True, False, None),
+    ("small proj_l2 bwd", 0, 4096, 1280, 1280, False, False, None),
+    ("small qkv_l2 bwd", 0, 4096, 1280, 3840, False, False, None),
+    ("small ff2_l2 bwd", 0, 4096, 5120, 1280, False, False, None),
 ]
 
 
@@ -73,15 +87,22 @@ def main():
         R = r(M, N, seed=3) if res else None
         outs, times = {}, {v: [] for v in variants}
         ok_variants = []
+
+        def call(v, out):   # -1 = the library's own choice with the split-K path kept on gemm3 + splitk_reduce (round 2)
+            return ops.gemm(x, w, residual=R, geglu=geglu, cfg=max(v, 0), out=out, g3_splitk=v < 0, **kw)
         for v in variants:
             if geglu and v in (12, 13, 14):
+                continue
+            if geglu and v in (1, 4, 0) and False:
+                continue
+            if v < 0 and geglu:
                 continue
             if v == 10 and (K != 320 or mode != 0):
                 continue
             if v in (12, 13, 14) and mode not in (0, 1):
                 continue
             try:
-                outs[v] = ops.gemm(x, w, residual=R, geglu=geglu, cfg=v, **kw).clone()
+                outs[v] = call(v, None).clone()
                 ok_variants.append(v)
             except RuntimeError as e:
                 print("# %s variant %d: %s" % (name, v, e), flush=True)
@@ -90,10 +111,10 @@ def main():
         out = torch.empty_like(outs[ok_variants[0]])
         for _ in range(a.rounds):
             for v in ok_variants:
-                ops.gemm(x, w, residual=R, geglu=geglu, cfg=v, out=out, **kw)
+                call(v, out)
                 e0.record()
                 for _ in range(a.iters):
-                    ops.gemm(x, w, residual=R, geglu=geglu, cfg=v, out=out, **kw)
+                    call(v, out)
                 e1.record()
                 torch.cuda.synchronize()
                 times[v].append(1e3 * e0.elapsed_time(e1) / a.iters)
@@ -102,7 +123,7 @@ def main():
         base = outs.get(1)
         for v in ok_variants:
             us = statistics.median(times[v])
-            row["v%d_us" % v] = round(us, 1)
+            row["v%d_us" % v] = round(us, 1)   # "v-1" = round-2 split-K
             row["v%d_TF" % v] = round(flop / us / 1e6, 0)
             if base is not None and v != 1:
                 d = (outs[v].float() - base.float()).abs().max().item()
