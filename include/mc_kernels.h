@@ -179,7 +179,9 @@ int mc_clip_embed_f16(const long* ids, const void* tok, const void* pos, void* o
                       void* stream);
 int mc_quick_gelu_f16(const void* in, void* out, long n, void* stream);
 /* reference-video front end behind the decoder (util.py:232-238): uint8 frames [N, Hs, Ws, 3] -> bilinear
- * (align_corners=True) -> [N, 3, H, W] fp16 in [-1, 1]; quantise != 0 re-rounds to 0..255 like the reference's uint8 resize */
+ * (align_corners=True) -> [N, 3, H, W] fp16 in [-1, 1].  quantise: 2 = bit-exact with torch's CPU uint8 bilinear resize (separable,
+ * horizontal pass first rounded to uint8, 16-bit fixed-point weights: what the reference's F.interpolate on the uint8 frames computes),
+ * 0 = float result, 1 = float result rounded to the nearest level, 3 = float result truncated */
 int mc_video_resize_u8_f16(const void* in, void* out, int N, int Hs, int Ws, int H, int W, int quantise, void* stream);
 /* latent_dist.sample() / .mode() of AutoencoderKL.encode (motionclone_functions.py:64,125): moment tokens
  * [(f p), 2*LAT] (mean | logvar) and an optional standard-normal draw [n, LAT, HW] -> [n, LAT, HW] */

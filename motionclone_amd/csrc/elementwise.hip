@@ -238,8 +238,47 @@ __global__ void video_resize_kernel(const uint8_t* in, half_t* out, int N, int H
         float v00 = f[((size_t)y0 * Ws + x0) * 3 + c], v01 = f[((size_t)y0 * Ws + x1) * 3 + c];
         float v10 = f[((size_t)y1 * Ws + x0) * 3 + c], v11 = f[((size_t)y1 * Ws + x1) * 3 + c];
         float v = (1.f - wy) * ((1.f - wx) * v00 + wx * v01) + wy * ((1.f - wx) * v10 + wx * v11);
-        if (quantise) v = rintf(v);
+        if (quantise == 1) v = rintf(v);
+        if (quantise == 3) v = floorf(v);
         out[idx] = (half_t)(v / 127.5f - 1.0f);
+    }
+}
+
+// quantise == 2: BIT-EXACT with torch's CPU uint8 bilinear path (F.interpolate on the channels-last uint8 frames, which is what
+// util.py:232-238 calls; verified against torch 2.10 in tests/test_kernels.py::test_video_resize): separable, HORIZONTAL pass first
+// with its result rounded to uint8, then the vertical pass; taps (i0, i0 + 1) with weights (1 - l, l), l = frac(i (in - 1) / (out - 1))
+// in double, as 16-bit fixed point with `prec` fractional bits (the largest precision whose biggest weight stays below 2^15,
+// found on the host: resize_precision), w = (int)(weight 2^prec + 0.5), accumulator preset to 2^(prec - 1), result >> prec,
+// clamped to 0..255.  One thread per output element evaluates the horizontal pass for its two source rows itself: no
+// intermediate image, no workspace.
+__device__ __forceinline__ void resize_taps(int i, double scale, int insz, int prec, int& i0, int& i1, int& w0, int& w1) {
+    const double real = scale * (double)i;
+    i0 = min((int)real, insz - 1);
+    i1 = min(i0 + 1, insz - 1);
+    const double l = real - (double)i0;
+    const double one = (double)(1 << prec);
+    w0 = (int)((1.0 - l) * one + 0.5);
+    w1 = (int)(l * one + 0.5);
+}
+__global__ void video_resize_exact_kernel(const uint8_t* in, half_t* out, int N, int Hs, int Ws, int H, int W, double sy,
+                                          double sx, int py, int px) {
+    const long total = (long)N * 3 * H * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long)gridDim.x * blockDim.x) {
+        int x = (int)(idx % W);
+        long r = idx / W;
+        int y = (int)(r % H);
+        r /= H;
+        int c = (int)(r % 3);
+        int n = (int)(r / 3);
+        int x0, x1, wx0, wx1, y0, y1, wy0, wy1;
+        resize_taps(x, sx, Ws, px, x0, x1, wx0, wx1);
+        resize_taps(y, sy, Hs, py, y0, y1, wy0, wy1);
+        const uint8_t* f = in + (size_t)n * Hs * Ws * 3;
+        const int ra = min(max(((1 << (px - 1)) + f[((size_t)y0 * Ws + x0) * 3 + c] * wx0 + f[((size_t)y0 * Ws + x1) * 3 + c] * wx1) >> px, 0), 255);
+        const int rb = min(max(((1 << (px - 1)) + f[((size_t)y1 * Ws + x0) * 3 + c] * wx0 + f[((size_t)y1 * Ws + x1) * 3 + c] * wx1) >> px, 0), 255);
+        const int v = min(max(((1 << (py - 1)) + ra * wy0 + rb * wy1) >> py, 0), 255);
+        out[idx] = (half_t)((float)v / 127.5f - 1.0f);
     }
 }
 
@@ -488,9 +527,30 @@ extern "C" int mc_vae_sample_f16(const void* moments, int ld, const void* noise,
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
+// weight precision of one axis of the exact resize (see video_resize_exact_kernel): plain double arithmetic on the host
+static int resize_precision(int insz, int outsz, double scale) {
+    double wt_max = 0.0;
+    for (int i = 0; i < outsz; ++i) {
+        const double real = scale * (double)i;
+        const int i0 = std::min((int)real, insz - 1);
+        const double l = real - (double)i0;
+        wt_max = std::max(wt_max, std::max(l, 1.0 - l));
+    }
+    int prec = 0;
+    for (prec = 0; prec < 22; ++prec)
+        if ((int)(0.5 + wt_max * (double)(1 << (prec + 1))) >= (1 << 15)) break;
+    return prec;
+}
+
 extern "C" int mc_video_resize_u8_f16(const void* in, void* out, int N, int Hs, int Ws, int H, int W, int quantise,
                                       void* stream) {
-    if (N <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0) return MC_ERR_SHAPE;
+    if (N <= 0 || Hs <= 0 || Ws <= 0 || H <= 0 || W <= 0 || quantise < 0 || quantise > 3) return MC_ERR_SHAPE;
+    if (quantise == 2) {
+        const double sy = H > 1 ? (double)(Hs - 1) / (double)(H - 1) : 0.0, sx = W > 1 ? (double)(Ws - 1) / (double)(W - 1) : 0.0;
+        MC_LAUNCH(video_resize_exact_kernel, dim3(ew_blocks((long)N * 3 * H * W)), dim3(256), 0, (hipStream_t)stream,
+                  (const uint8_t*)in, (half_t*)out, N, Hs, Ws, H, W, sy, sx, resize_precision(Hs, H, sy), resize_precision(Ws, W, sx));
+        return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+    }
     MC_LAUNCH(video_resize_kernel, dim3(ew_blocks((long)N * 3 * H * W)), dim3(256), 0, (hipStream_t)stream,
               (const uint8_t*)in, (half_t*)out, N, Hs, Ws, H, W, quantise);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;

@@ -23,6 +23,7 @@
 // order.  Split-K and odd shapes (N % 8, ldc % 8) stay on gemm3.
 #include "gemm_params.hpp"
 #include <type_traits>
+#include <cstdlib>
 
 namespace mc {
 
@@ -129,7 +130,7 @@ __device__ __forceinline__ void g5_epilogue(const GemmParams& p, f32x16 (&acc)[g
 // default), bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
 template <int MODE, int EPI, int VAR, int BM>
 __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2, uint32_t bytesW,
-                                                        int tilesM, int tilesN) {
+                                                        int tilesM, int tilesN, int sm, int sn) {
     using namespace g5;
     using T = Tile<BM>;
     constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB;
@@ -144,14 +145,24 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
 #endif
     const bool grpA = wave < 4;
     const int pid = blockIdx.x;
-    const int xcd = pid & 7, local = pid >> 3;
-    const int tn = local % tilesN;
-    int tm;   // tile order: see gemm3.hip
+    const int xcd = pid & 7, local = pid >> 3;   // workgroup b runs on XCD b % 8 (observed; a speed assumption only)
+    int tm, tn;
     if (MODE == DENSE || tilesN > 1) {
-        tm = (local / tilesN) * 8 + xcd;
+        // Every XCD owns the M-tiles tm = 8 i + xcd and walks them in SUPER-TILES of sm x sn tiles (about the 32 workgroups
+        // its CUs hold at a time): the activation rows of sm tiles and the weight rows of sn tiles are what the XCD's L2 serves
+        // to those 32 tiles.  With one M-tile at a time (sm = 1: round 2's order) an XCD re-streams ALL of W for every
+        // M-tile - PMC: 944 MB per launch against 131 MB algorithmic on the 8192 x 10240 x 1280 GEGLU layer (7.2x), 2.6-2.9x
+        // on the other wide layers (profiles/r03_pmc_hbm_traffic.md).  sm, sn are chosen on the host (launch5).
+        const int per_group = sm * tilesN;
+        const int g = local / per_group, idx = local - g * per_group;
+        const int blk = idx / (sm * sn), w = idx - blk * (sm * sn);
+        tn = blk * sn + w / sm;
+        tm = (g * sm + w % sm) * 8 + xcd;
     } else {
+        // single-N-tile convolutions: a CONTIGUOUS range of M-tiles per XCD (halo rows of vertically adjacent tiles meet in L2)
+        tn = 0;
         const int per = (tilesM + 7) >> 3;
-        tm = (local / tilesN) < per ? xcd * per + local / tilesN : tilesM;
+        tm = local < per ? xcd * per + local : tilesM;
     }
     if (tm >= tilesM) return;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -454,8 +465,22 @@ static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, 
     using T = g5::Tile<BM>;
     int tM = (p.M + BM - 1) / BM, tN = (p.N + g5::BN - 1) / g5::BN;
     allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM>, T::SMEM);
-    dim3 grid((unsigned)(((tM + 7) / 8) * 8 * tN), (unsigned)p.splits);
-    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM>), grid, dim3(g5::NT), T::SMEM, stream, p, bA, bA2, bW, tM, tN);
+    // super-tile of the XCD-local tile order: sn divides the N-tiles, sm x sn ~ 32 workgroups, least operand rows per tile
+    const int rows_per_xcd = (tM + 7) / 8;
+    int sm = 1, sn = 1;
+    static const int no_swz = getenv("MC_GEMM5_NO_SUPERTILE") ? atoi(getenv("MC_GEMM5_NO_SUPERTILE")) : 0;   // A/B only
+    if ((MODE == DENSE || tN > 1) && !no_swz) {
+        long best = -1;
+        for (int c = 1; c <= tN && c <= 16; ++c) {
+            if (tN % c) continue;
+            int r = std::max(1, std::min(rows_per_xcd, (32 + c / 2) / c));
+            long cost = ((long)r * BM + (long)c * g5::BN) * 1000 / ((long)r * c);   // operand rows fetched per tile of the super-tile
+            if (best < 0 || cost < best) best = cost, sm = r, sn = c;
+        }
+    }
+    const int groups = (rows_per_xcd + sm - 1) / sm;
+    dim3 grid((unsigned)(groups * sm * 8 * tN), (unsigned)p.splits);
+    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM>), grid, dim3(g5::NT), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
     if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
     if (p.ws) {
         MC_LAUNCH((splitk_reduce5_kernel<T::TM>), dim3((unsigned)(tM * tN * g5::NW)), dim3(64), (size_t)g5::STG, stream, p, tM, tN);

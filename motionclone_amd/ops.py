@@ -384,13 +384,17 @@ def video_post(tokens, C, F, H, W):
     return out
 
 
-def video_resize(frames_u8, H, W, quantise=True):
-    """uint8 [N, Hs, Ws, 3] (device) -> fp16 [N, 3, H, W] in [-1, 1]: bilinear align_corners=True, / 127.5 - 1"""
+def video_resize(frames_u8, H, W, quantise=2):
+    """uint8 [N, Hs, Ws, 3] (device) -> fp16 [N, 3, H, W] in [-1, 1]: bilinear align_corners=True, / 127.5 - 1.
+    quantise: 2 (default) = BIT-EXACT with torch's CPU uint8 resize (what util.py:232-238 runs on the decord frames: separable
+    fixed-point passes, checked against the installed torch); 0 = no re-quantisation (float result), 1 = float result rounded
+    to nearest level, 3 = float result truncated (the generic-template semantics of torch 2.0.x as far as its source tells -
+    not verifiable offline)."""
     assert frames_u8.dtype == torch.uint8 and frames_u8.dim() == 4 and frames_u8.shape[3] == 3
     frames_u8 = frames_u8.contiguous()
     N, Hs, Ws, _ = frames_u8.shape
     out = torch.empty((N, 3, H, W), dtype=torch.float16, device=frames_u8.device)
-    lib.call("mc_video_resize_u8_f16", _p(frames_u8), _p(out), N, Hs, Ws, H, W, int(quantise), _stream(frames_u8))
+    lib.call("mc_video_resize_u8_f16", _p(frames_u8), _p(out), N, Hs, Ws, H, W, int(2 if quantise is True else quantise), _stream(frames_u8))
     return out
 
 

@@ -544,25 +544,34 @@ def test_cfg_ddim_step(backend):
     close(out2, math.sqrt(a_prev) * x0 + math.sqrt(1 - a_prev) * eps, 2e-2, 3e-3, "cfg+ddim plain")
 
 
-def test_video_resize(backend):
-    """reference-video front end (util.py:232-238): bilinear align_corners resize of uint8 frames + normalisation"""
+@pytest.mark.parametrize("sizes", [(37, 53, 32, 48), (90, 160, 64, 64), (48, 48, 64, 96), (123, 77, 50, 91), (20, 24, 16, 16)])
+def test_video_resize(backend, sizes):
+    """reference-video front end (util.py:232-238): F.interpolate(bilinear, align_corners=True) ON THE uint8 FRAMES, then
+    / 127.5 - 1.  Byte work: the kernel's default mode reproduces torch's CPU uint8 result EXACTLY - the resized level of
+    every element, recovered from the fp16 output, equals torch's uint8 value (down- and up-scaling, odd sizes)."""
     dev = backend
-    g = torch.Generator().manual_seed(0)
-    x = torch.randint(0, 256, (3, 37, 53, 3), generator=g, dtype=torch.uint8)
-    got = ops.video_resize(x.to(dev), 32, 48)
+    hs, ws, H, W = sizes
+    g = torch.Generator().manual_seed(hs * 1000 + ws)
+    x = torch.randint(0, 256, (3, hs, ws, 3), generator=g, dtype=torch.uint8)
+    got = ops.video_resize(x.to(dev), H, W)
+    assert got.shape == (3, 3, H, W) and got.dtype == torch.float16
+    u8 = Fn.interpolate(x.permute(0, 3, 1, 2), size=(H, W), mode="bilinear", align_corners=True)   # the reference's call
+    assert u8.dtype == torch.uint8
+    want = (u8.float() / 127.5 - 1.0).half()                 # video / 127.5 - 1.0, stored as the fp16 the VAE consumes
+    assert torch.equal(got.cpu(), want), "resize differs from torch's uint8 path in %d elements" % int((got.cpu() != want).sum())
+    levels = torch.round((got.float().cpu() + 1.0) * 127.5).to(torch.uint8)
+    assert torch.equal(levels, u8)
+    # the float modes: un-quantised, rounded, truncated
     xf = x.permute(0, 3, 1, 2).float()
-    ref = Fn.interpolate(xf, size=(32, 48), mode="bilinear", align_corners=True)
-    assert got.shape == (3, 3, 32, 48) and got.dtype == torch.float16
-    want = ref.round() / 127.5 - 1.0
-    assert (got.float().cpu() - want).abs().max() < 1.01 / 127.5 + 1e-3          # at most one level at .5 ties
-    assert ((got.float().cpu() - want).abs() > 2e-3).float().mean() < 0.01
-    u8 = Fn.interpolate(x.permute(0, 3, 1, 2), size=(32, 48), mode="bilinear", align_corners=True).float() / 127.5 - 1.0
-    assert (got.float().cpu() - u8).abs().max() < 1.01 / 127.5 + 1e-3             # torch's own uint8 path: +-1 level
-    smooth = ops.video_resize(x.to(dev), 32, 48, quantise=False)
+    ref = Fn.interpolate(xf, size=(H, W), mode="bilinear", align_corners=True)
+    smooth = ops.video_resize(x.to(dev), H, W, quantise=0)
     assert (smooth.float().cpu() - (ref / 127.5 - 1.0)).abs().max() < 2e-3
+    for q, fn in ((1, torch.round), (3, torch.floor)):
+        alt = ops.video_resize(x.to(dev), H, W, quantise=q).float().cpu()
+        assert ((alt - (fn(ref) / 127.5 - 1.0)).abs() > 2e-3).float().mean() < 0.01      # float ties at .0 / .5 boundaries only
     from motionclone_amd.utils.util import pick_frames, preprocess_frames
     assert pick_frames(100, 4).tolist() == [0, 33, 66, 99] and pick_frames(100, 3, fps=10.0, duration=2.05).tolist() == [0, 9, 19]
-    assert torch.equal(preprocess_frames(x.numpy(), 32, 48, device=dev), got)
+    assert torch.equal(preprocess_frames(x.numpy(), H, W, device=dev), got)
 
 
 @pytest.mark.parametrize("F_,d", [(16, 160), (16, 40), (24, 32), (32, 160), (32, 40)])
