@@ -45,3 +45,99 @@ def max_over_ranks(value, device="cpu"):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         return float(t.item())
     return float(value)
+
+
+# ---- checkpoint files: read once (rank 0), broadcast, shared by the lanes of a process ------------------------------------
+def _pack(obj, tensors):
+    """nested dict / list / tuple with the tensors replaced by (index, shape, dtype) stubs; tensors collected in order"""
+    if isinstance(obj, torch.Tensor):
+        tensors.append(obj.detach().cpu().contiguous())
+        return ("__tensor__", len(tensors) - 1, tuple(obj.shape), obj.dtype)
+    if isinstance(obj, dict):
+        return {k: _pack(v, tensors) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_pack(v, tensors) for v in obj)
+    return obj
+
+
+def _unpack(obj, flat, offsets):
+    if isinstance(obj, tuple) and len(obj) == 4 and obj[0] == "__tensor__":
+        _, i, shape, dtype = obj
+        n = int(torch.Size(shape).numel()) * torch.empty((), dtype=dtype).element_size()
+        return flat[offsets[i]:offsets[i] + n].view(dtype).view(shape)
+    if isinstance(obj, dict):
+        return {k: _unpack(v, flat, offsets) for k, v in obj.items()}
+    if isinstance(obj, list):
+        return [_unpack(v, flat, offsets) for v in obj]
+    if isinstance(obj, tuple):
+        return tuple(_unpack(v, flat, offsets) for v in obj)
+    return obj
+
+
+def broadcast_state(obj=None, src=0, device=None):
+    """One object + ONE byte-buffer broadcast for a whole checkpoint (nested containers of tensors): `obj` is read on `src`
+    only, every other rank passes None and gets an equal copy (CPU tensors, views into one buffer).  `device`: where the
+    buffer travels (RCCL needs device memory: "cuda"; gloo: None = host)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return obj
+    rank = dist.get_rank()
+    meta = [None]
+    flat = None
+    if rank == src:
+        tensors = []
+        skel = _pack(obj, tensors)
+        offsets, off = [], 0
+        for t in tensors:
+            offsets.append(off)
+            off += (t.numel() * t.element_size() + 15) // 16 * 16
+        flat = torch.empty(max(off, 16), dtype=torch.uint8)
+        for t, o in zip(tensors, offsets):
+            flat[o:o + t.numel() * t.element_size()] = t.view(-1).view(torch.uint8)
+        meta = [(skel, offsets, flat.numel())]
+    dist.broadcast_object_list(meta, src=src)
+    skel, offsets, nbytes = meta[0]
+    if rank != src:
+        flat = torch.empty(nbytes, dtype=torch.uint8)
+    if device is not None:
+        buf = flat.to(device)
+        dist.broadcast(buf, src=src)
+        flat = buf.cpu()
+    else:
+        dist.broadcast(flat, src=src)
+    return obj if rank == src else _unpack(skel, flat, offsets)
+
+
+class SharedCheckpoints:
+    """`load(key, reader)`: the checkpoint file `key` is READ ONCE PER JOB - by rank 0 - and reaches the other ranks by
+    `broadcast_state` (the one collective of the path); inside a process it is loaded once and shared by all
+    launcher lanes.  Collectives are only ever issued by lane 0's thread (every rank's lane 0 walks the script in the same
+    order, so the broadcasts pair up); other lanes wait until lane 0 has published the key."""
+
+    def __init__(self, device=None):
+        import threading
+        self._cv = threading.Condition()
+        self._cache = {}
+        self._device = device
+        self.reads = 0          # files actually read from disk by this process
+        self.received = 0       # files received from rank 0
+
+    def load(self, key, reader, is_leader=True):
+        with self._cv:
+            if key in self._cache:
+                return self._cache[key]
+            if not is_leader:
+                self._cv.wait_for(lambda: key in self._cache)
+                return self._cache[key]
+        multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        if not multi or dist.get_rank() == 0:
+            obj = reader()
+            self.reads += 1
+            if multi:
+                broadcast_state(obj, 0, self._device)
+        else:
+            obj = broadcast_state(None, 0, self._device)
+            self.received += 1
+        with self._cv:
+            self._cache[key] = obj
+            self._cv.notify_all()
+        return obj

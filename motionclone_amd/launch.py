@@ -7,25 +7,36 @@
 One process per GPU.  Rank r runs the script's own `main(args)` on the lines i of the examples file with
 i mod world == r (the reference walks them sequentially, t2v_video_sample.py:75-105), pinned to GPU LOCAL_RANK through
 the script's `--visible_gpu`, writing its motion representations under `<dir>/rank<r>/` (several lines share a reference
-video and the reference overwrites `<stem>.pt` per example, :89).  Every rank loads the checkpoints itself; the only
-collective is a max-reduce of the wall time at the end (RCCL: backend "nccl"; gloo without GPUs).
+video and the reference overwrites `<stem>.pt` per example, :89).  Checkpoint files are read from disk by rank 0 only and reach
+the other ranks by one broadcast per file (RCCL: backend "nccl"; gloo without GPUs; `--no-broadcast-weights`: every rank reads
+them itself); the only other collective is a max-reduce of the wall time at the end.
+
+`--lanes K` (default 1): K examples IN FLIGHT per process, each in its own host thread + HIP stream running the same unmodified
+script on every K-th of the rank's lines (motionclone_amd/lanes.py): the kernels of one example leave CUs idle in tails and in
+the small 16x16 / 8x8-level launches, which the other lanes fill - the regime bench.py times (`--inflight`).  The DDIM steps
+replay from hipGraphs (captured per lane at first use).  Every lane loads its own copy of the checkpoints (HBM is 288 GB).
 
 Serial-RNG fidelity: the scripts seed the GLOBAL generator once (`set_all_seed(42)`) and the VAE
 posterior of every example draws from it, so an example's motion representation depends on how many examples ran
 before it.  With `--serial-rng` (default on) a rank burns, for every line it skips, the draws that line would have made
 (one `[L, 4, H/8, W/8]` normal tensor for the reference video, plus `[n_images, 4, H/8, W/8]` for i2v condition images),
-so that the sharded run reproduces the single-process run bit for bit."""
+so that the sharded run reproduces the single-process run bit for bit.  Lanes shard the same way (line i -> rank i mod world,
+lane (i div world) mod K) and each lane keeps a PRIVATE copy of the "global" stream (lanes.py), so `--lanes K` is bit-identical
+to the serial run as well (tests/test_entry_scripts.py)."""
+import argparse
 import builtins
 import io
 import json
 import os
 import runpy
 import sys
+import threading
 import time
 
 import torch
 
 from . import dist as mcd
+from . import lanes as mcl
 
 
 def _arg(argv, names, default=None):
@@ -103,6 +114,14 @@ def main(argv=None):
     if "--vae-scale" in argv:
         i = argv.index("--vae-scale")
         del argv[i:i + 2]
+    broadcast_weights = True
+    if "--no-broadcast-weights" in argv:
+        argv.remove("--no-broadcast-weights")
+        broadcast_weights = False
+    n_lanes = int(_arg(argv, ["--lanes"], 1))
+    if "--lanes" in argv:
+        i = argv.index("--lanes")
+        del argv[i:i + 2]
     script, sargv = argv[0], argv[1:]
     # Pin the GPU BEFORE anything initialises the HIP runtime: the runtime reads CUDA_VISIBLE_DEVICES once, and both
     # torch.cuda.is_available() and the scripts' own late `os.environ["CUDA_VISIBLE_DEVICES"] = args.visible_gpu` (inside
@@ -122,12 +141,11 @@ def main(argv=None):
     with open(examples) as f:
         lines = f.readlines()
     mine = mcd.shard_examples([ln for ln in lines if ln.strip()], rank, world)
-    if world > 1:
-        sargv = _set_arg(sargv, "--motion-representation-save-dir", os.path.join(rep_dir, "rank%d" % rank))
-        if torch.cuda.is_available():
-            # the script assigns CUDA_VISIBLE_DEVICES = args.visible_gpu inside main(): hand it the value set above, so
-            # the assignment is a no-op whether or not the runtime is already up
-            sargv = _set_arg(sargv, "--visible_gpu", os.environ["CUDA_VISIBLE_DEVICES"])
+    on_gpu = torch.cuda.is_available()
+    if world > 1 and on_gpu:
+        # the script assigns CUDA_VISIBLE_DEVICES = args.visible_gpu inside main(): hand it the value set above, so
+        # the assignment is a no-op whether or not the runtime is already up
+        sargv = _set_arg(sargv, "--visible_gpu", os.environ["CUDA_VISIBLE_DEVICES"])
     # Only the latent-condition SparseCtrl (use_simplified_condition_embedding: true, sparsectrl/latent_condition.yaml)
     # VAE-encodes the condition images and so draws from the global generator (motionclone_functions.py:122-126); the
     # pixel-condition variant (image_condition.yaml, :127-128) draws nothing for them.
@@ -136,35 +154,110 @@ def main(argv=None):
         encodes_condition = _condition_images_are_encoded(_arg(sargv, ["--inference_config"], "configs/i2v_sketch.yaml"))
 
     def burn(example):
-        dev = "cuda" if torch.cuda.is_available() else "cpu"
-        torch.randn((L, 4, H // vae_scale, W // vae_scale), device=dev, dtype=torch.float16)
+        dev = "cuda" if on_gpu else "cpu"
+        gen = mcl.serial_generator()      # the lane's private stream, or None = torch's global generator
+        torch.randn((L, 4, H // vae_scale, W // vae_scale), device=dev, dtype=torch.float16, generator=gen)
         n_img = len(example.get("condition_image_paths", ())) if encodes_condition else 0
         if n_img:
-            torch.randn((n_img, 4, H // vae_scale, W // vae_scale), device=dev, dtype=torch.float16)
+            torch.randn((n_img, 4, H // vae_scale, W // vae_scale), device=dev, dtype=torch.float16, generator=gen)
 
+    # virtual rank of (rank, lane): line i belongs to it iff i mod (world K) == rank + world lane
+    vworld = world * n_lanes
+    sharded = vworld > 1
     real_open = builtins.open
     ex_abs = os.path.abspath(examples)
 
     def sharded_open(path, *a, **k):
-        if world > 1 and isinstance(path, (str, os.PathLike)) and os.path.abspath(path) == ex_abs and (not a or "r" in a[0]):
-            return _ShardedLines(lines, rank, world, burn if serial_rng else None)
+        if sharded and isinstance(path, (str, os.PathLike)) and os.path.abspath(path) == ex_abs and (not a or "r" in a[0]):
+            vrank = rank + world * (mcl.lane_index() or 0)
+            return _ShardedLines(lines, vrank, vworld, burn if serial_rng else None)
         return real_open(path, *a, **k)
 
+    def lane_argv(lane):
+        out = sargv
+        if sharded:
+            sub = "rank%d" % rank if n_lanes == 1 else "rank%d_lane%d" % (rank, lane)
+            out = _set_arg(out, "--motion-representation-save-dir", os.path.join(rep_dir, sub))
+        return out
+
+    # Checkpoint files are read once per JOB: rank 0 reads, the other ranks receive them by one broadcast each, the lanes of a
+    # process share them (checkpoints.py / dist.SharedCheckpoints).  The scripts' own direct torch.load calls (the SparseCtrl
+    # checkpoint, i2v_video_sample.py) go the same way; the per-example motion-representation files do not.
+    from . import checkpoints as mck
+    share_ckpt = broadcast_weights and (world > 1 or n_lanes > 1)
+    real_torch_load = torch.load
+    rep_abs = os.path.abspath(rep_dir)
+
+    def shared_torch_load(f, *a, **k):
+        if share_ckpt and isinstance(f, (str, os.PathLike)) and not os.path.abspath(os.fspath(f)).startswith(rep_abs):
+            return mck.read(f)
+        return real_torch_load(f, *a, **k)
+
+    # the scripts read sys.argv through argparse; lanes need different argument lists, so parse_known_args looks at a
+    # thread-local list first
+    targv = threading.local()
+    real_parse = argparse.ArgumentParser.parse_known_args
+
+    def parse_known_args(self, args=None, namespace=None):
+        if args is None and getattr(targv, "argv", None) is not None:
+            args = list(targv.argv)
+        return real_parse(self, args, namespace)
+
+    errors = []
+
+    def run_lane(lane):
+        try:
+            if n_lanes > 1:
+                mcl.begin(lane, n_lanes, "cuda" if on_gpu else "cpu")
+                if on_gpu:
+                    torch.cuda.set_stream(torch.cuda.Stream())
+            targv.argv = lane_argv(lane)
+            runpy.run_path(script, run_name="__main__")
+            if on_gpu:
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:   # noqa: BLE001 - reported by the main thread
+            errors.append((lane, e))
+        finally:
+            mcl.end()
+
     builtins.open = sharded_open
+    argparse.ArgumentParser.parse_known_args = parse_known_args
+    shared = None
+    if share_ckpt:
+        shared = mcd.SharedCheckpoints(device="cuda" if on_gpu and world > 1 else None)
+        mck.install(shared)
+        torch.load = shared_torch_load
     t0 = time.perf_counter()
     try:
-        sys.argv = [script] + sargv
-        runpy.run_path(script, run_name="__main__")
+        sys.argv = [script] + lane_argv(0)
+        if n_lanes == 1:
+            run_lane(0)
+        else:
+            from . import ops
+            ops.set_gemm_share(n_lanes)     # tile / split-K choice for n_lanes launch sequences in flight (before any graph capture)
+            threads = [threading.Thread(target=run_lane, args=(k,), name="lane%d" % k) for k in range(n_lanes)]
+            for t in threads:
+                t.start()
+            for t in threads:
+                t.join()
+        if errors:
+            raise errors[0][1]
     finally:
         builtins.open = real_open
-    if torch.cuda.is_available():
+        argparse.ArgumentParser.parse_known_args = real_parse
+        torch.load = real_torch_load
+        mck.install(None)
+    if on_gpu:
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    slowest = mcd.max_over_ranks(dt, device="cuda" if torch.cuda.is_available() and world > 1 else "cpu")
+    slowest = mcd.max_over_ranks(dt, device="cuda" if on_gpu and world > 1 else "cpu")
     if rank == 0:
         n = len([ln for ln in lines if ln.strip()])
-        print(json.dumps(dict(examples=n, world=world, seconds=slowest, videos_per_min=60.0 * n / slowest,
-                              examples_of_rank0=[i for i, _ in mine])))
+        print(json.dumps(dict(examples=n, world=world, lanes=n_lanes, seconds=slowest, videos_per_min=60.0 * n / slowest,
+                              examples_of_rank0=[i for i, _ in mine],
+                              checkpoint_files_read_by_rank0=shared.reads if shared else None)))
+    elif shared is not None:
+        print(json.dumps(dict(rank=rank, checkpoint_files_read_from_disk=shared.reads, received_by_broadcast=shared.received)))
     if world > 1 and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 

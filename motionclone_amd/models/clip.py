@@ -68,11 +68,8 @@ class CLIPTextModel(nn.Module):
         config = config.get("text_config", config)
         model = cls(**config)
         st = os.path.join(pretrained_model_path, "model.safetensors")
-        if os.path.isfile(st):
-            from safetensors.torch import load_file
-            sd = load_file(st)
-        else:
-            sd = torch.load(os.path.join(pretrained_model_path, "pytorch_model.bin"), map_location="cpu")
+        from .. import checkpoints
+        sd = checkpoints.read(st if os.path.isfile(st) else os.path.join(pretrained_model_path, "pytorch_model.bin"))
         model.load_state_dict(sd)
         return model
 

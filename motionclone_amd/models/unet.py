@@ -146,7 +146,8 @@ class UNet3DConditionModel(nn.Module):
         model_file = os.path.join(pretrained_model_path, "diffusion_pytorch_model.bin")
         if not os.path.isfile(model_file):
             raise RuntimeError(f"{model_file} does not exist")
-        state_dict = torch.load(model_file, map_location="cpu")
+        from .. import checkpoints
+        state_dict = checkpoints.read(model_file)
         m, u = model.load_state_dict(state_dict, strict=False)
         print(f"### motion keys will be loaded: {len(m)}; \n### unexpected keys: {len(u)};")
         return model

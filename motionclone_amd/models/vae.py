@@ -140,7 +140,8 @@ class AutoencoderKL(nn.Module):
         model_file = os.path.join(pretrained_model_path, "diffusion_pytorch_model.bin")
         if not os.path.isfile(model_file):
             raise RuntimeError(f"{model_file} does not exist")
-        model.load_state_dict(torch.load(model_file, map_location="cpu"))
+        from .. import checkpoints
+        model.load_state_dict(checkpoints.read(model_file))
         return model
 
     def load_state_dict(self, state_dict, strict=True, **kw):

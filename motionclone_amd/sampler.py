@@ -116,7 +116,8 @@ class MotionCloneSampler:
                 first = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
             torch.cuda.current_stream().wait_stream(side)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph, pool=self._graph_pool):
+            # thread_local: other host threads (launcher lanes) keep allocating / launching while this one captures
+            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
                 s_out = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
             if self._graph_pool is None:
                 self._graph_pool = graph.pool()

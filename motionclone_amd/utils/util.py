@@ -14,7 +14,9 @@ def classify_blocks(block_list, name):
 
 
 def set_all_seed(seed):
-    """reference util.py:442-447"""
+    """reference util.py:442-447 (inside a launcher lane the thread's private serial stream is seeded as well: lanes.py)"""
+    from .. import lanes
+    lanes.seed(seed)
     torch.manual_seed(seed)
     if torch.cuda.is_available():
         torch.cuda.manual_seed(seed)
@@ -87,14 +89,8 @@ def save_videos_grid(videos, path, rescale=False, n_rows=6, fps=8):
 
 
 def _load_checkpoint_file(path):
-    if path.endswith(".safetensors"):
-        from safetensors import safe_open
-        sd = {}
-        with safe_open(path, framework="pt", device="cpu") as f:
-            for key in f.keys():
-                sd[key] = f.get_tensor(key)
-        return sd
-    return torch.load(path, map_location="cpu")
+    from .. import checkpoints
+    return checkpoints.read(path)
 
 
 def _unwrap(sd):
@@ -114,7 +110,7 @@ def load_weights(animation_pipeline, motion_module_path="", motion_module_lora_c
     pipeline = animation_pipeline
     if motion_module_path != "":
         print(f"load motion module from {motion_module_path}")
-        sd = _unwrap(torch.load(motion_module_path, map_location="cpu"))
+        sd = _unwrap(_load_checkpoint_file(motion_module_path))
         sd = {k: v for k, v in sd.items() if "motion_modules." in k}
         missing, unexpected = pipeline.unet.load_state_dict(sd, strict=False)
         if unexpected:   # tolerated like the reference (util.py:136-137 has the assert commented out)
@@ -137,12 +133,12 @@ def load_weights(animation_pipeline, motion_module_path="", motion_module_lora_c
         pipeline = convert_lora(pipeline, _load_checkpoint_file(lora_model_path), alpha=lora_alpha)
     if adapter_lora_path != "":
         print(f"load domain lora from {adapter_lora_path}")
-        pipeline = load_diffusers_lora(pipeline, _unwrap(torch.load(adapter_lora_path, map_location="cpu")),
+        pipeline = load_diffusers_lora(pipeline, _unwrap(_load_checkpoint_file(adapter_lora_path)),
                                        alpha=adapter_lora_scale)
     for cfg in motion_module_lora_configs:
         path, alpha = cfg["path"], cfg["alpha"]
         print(f"load motion LoRA from {path}")
-        pipeline = load_diffusers_lora(pipeline, _unwrap(torch.load(path, map_location="cpu")), alpha)
+        pipeline = load_diffusers_lora(pipeline, _unwrap(_load_checkpoint_file(path)), alpha)
     return pipeline
 
 

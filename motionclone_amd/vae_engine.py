@@ -173,6 +173,9 @@ class DiagonalGaussianDistribution:
         return (self._n, self._lat, self._h, self._w)
 
     def sample(self, generator=None):
+        if generator is None:   # the reference draws from the global generator; a launcher lane has its own copy of that stream
+            from . import lanes
+            generator = lanes.serial_generator()
         noise = torch.randn(self._shape(), generator=generator, device=self._tok.device, dtype=torch.float16)
         return ops.vae_sample(self._tok, noise, self._lat)
 

@@ -292,11 +292,13 @@ def install_recorders(rec):
 
 
 def main():
-    """entry_harness.py KIND WORKDIR [--examples N] [--launch]   (--launch: through motionclone_amd.launch, sharded over the
-    torchrun environment's ranks; the assets must already exist in WORKDIR, outputs go to WORKDIR/rank<r>_*)"""
+    """entry_harness.py KIND WORKDIR [--examples N] [--launch [--lanes K]]   (--launch: through motionclone_amd.launch, sharded
+    over the torchrun environment's ranks and K lanes per rank; the assets must already exist in WORKDIR, outputs go to
+    WORKDIR/videos_rank<r>)"""
     kind, work = sys.argv[1], os.path.abspath(sys.argv[2])
     n_examples = int(sys.argv[sys.argv.index("--examples") + 1]) if "--examples" in sys.argv else 1
     launch = "--launch" in sys.argv
+    n_lanes = sys.argv[sys.argv.index("--lanes") + 1] if "--lanes" in sys.argv else "1"
     os.makedirs(work, exist_ok=True)
     sys.path.insert(0, ROOT)        # `motionclone` must resolve to this repo's drop-in package, not to the reference's
     assert not any(os.path.abspath(p) == REFERENCE_ROOT for p in sys.path)
@@ -319,7 +321,7 @@ def main():
         L.main([script, "--pretrained-model-path", common["pretrained_model_path"], "--inference_config",
                 common["inference_config"], "--examples", common["examples"], "--motion-representation-save-dir",
                 os.path.join(work, "mr_sharded"), "--generated-videos-save-dir", os.path.join(work, "videos_rank%d" % rank),
-                "--L", str(F), "--W", str(px), "--H", str(px), "--vae-scale", "2"])
+                "--L", str(F), "--W", str(px), "--H", str(px), "--vae-scale", "8" if kind == "i2v_sketch" else "2", "--lanes", n_lanes])
         print("ENTRY_OK", kind, written)
         return
     ns = runpy.run_path(script, run_name="entry_script_under_test")

@@ -24,7 +24,17 @@ def _worker(rank, world, port, out):
     mine = mcd.shard_examples(lines, r, w)
     t = mcd.max_over_ranks(1.0 + r)
     path = mcd.representation_path("/tmp/mr", "reference_videos/camera_zoom_in.mp4", r, w)
-    out.put((r, float(flat.double().abs().sum()), [i for i, _ in mine], t, path))
+    # a whole checkpoint (nested containers, mixed dtypes) by one object + one byte-buffer broadcast; only rank 0 "reads" it
+    ck = None
+    if r == 0:
+        g = torch.Generator().manual_seed(5)
+        ck = {"state_dict": {"a.weight": torch.randn(7, 3, generator=g).half(), "b": torch.arange(5), "n": {"c": torch.randn(2, 2, generator=g)}},
+              "meta": ["v3", 1.5, (torch.ones(3, dtype=torch.uint8),)]}
+    shared = mcd.SharedCheckpoints()
+    got = shared.load("/nonexistent/ckpt.pt", lambda: ck)
+    digest = (float(got["state_dict"]["a.weight"].float().sum()), got["state_dict"]["b"].tolist(), got["meta"][:2],
+              float(got["state_dict"]["n"]["c"].sum()), got["meta"][2][0].dtype == torch.uint8, shared.reads, shared.received)
+    out.put((r, float(flat.double().abs().sum()), [i for i, _ in mine], t, path, digest))
     torch.distributed.destroy_process_group()
 
 
@@ -42,7 +52,8 @@ def test_two_rank_replicas_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, sum0, ex0, t0, p0), (r1, sum1, ex1, t1, p1) = res
+    (r0, sum0, ex0, t0, p0, d0), (r1, sum1, ex1, t1, p1, d1) = res
+    assert d0[:5] == d1[:5] and d0[5:] == (1, 0) and d1[5:] == (0, 1)   # same checkpoint; read once, received once
     assert sum0 == sum1 and sum0 > 0          # rank 1 received rank 0's weights
     assert ex0 == [0, 2, 4] and ex1 == [1, 3]  # round-robin sharding, every example exactly once
     assert t0 == t1 == 2.0                     # max over ranks

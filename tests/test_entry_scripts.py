@@ -191,6 +191,11 @@ def test_launcher_shards_examples_and_reproduces_the_serial_run(runs, kind):
     for p, o in zip(procs, outs):
         assert p.returncode == 0 and "ENTRY_OK" in o, o[-4000:]
     assert '"world": 2' in outs[0] and '"examples": 2' in outs[0]
+    # checkpoints: rank 0 read the files, rank 1 read nothing from disk and received every one of them by broadcast
+    import json as _json
+    r1 = [_json.loads(ln) for ln in outs[1].splitlines() if ln.startswith('{"rank": 1')][0]
+    r0 = [_json.loads(ln) for ln in outs[0].splitlines() if ln.startswith('{"examples"')][0]
+    assert r1["checkpoint_files_read_from_disk"] == 0 and r1["received_by_broadcast"] == r0["checkpoint_files_read_by_rank0"] >= 3
     serial = [np.load(v + ".npy") for v in rec["videos"]]
     for r in range(2):
         name = os.path.basename(rec["videos"][r])
@@ -199,3 +204,24 @@ def test_launcher_shards_examples_and_reproduces_the_serial_run(runs, kind):
         assert os.path.exists(os.path.join(str(work), "mr_sharded", "rank%d" % r, "clip.pt"))
         other = os.path.join(str(work), "videos_rank%d" % r, os.path.basename(rec["videos"][1 - r]) + ".npy")
         assert not os.path.exists(other)      # every example ran exactly once
+
+
+def test_launcher_lanes_reproduce_the_serial_run(runs):
+    """`motionclone_amd.launch --lanes 2` in ONE process: two host threads run the unmodified t2v script on alternate lines
+    of the examples file, each with a private copy of the serial RNG stream (motionclone_amd/lanes.py); both videos are
+    bit-identical to the single-process run and every example ran exactly once."""
+    work, rec = runs("t2v")
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), "t2v", str(work), "--launch",
+                          "--lanes", "2"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=str(work))
+    out = p.communicate(timeout=1500)[0]
+    assert p.returncode == 0 and "ENTRY_OK" in out, out[-4000:]
+    assert '"lanes": 2' in out and '"examples": 2' in out
+    serial = [np.load(v + ".npy") for v in rec["videos"]]
+    for k in range(2):
+        name = os.path.basename(rec["videos"][k])
+        got = np.load(os.path.join(str(work), "videos_rank0", name + ".npy"))
+        assert np.array_equal(got, serial[k]), "lane %d video differs from the serial run" % k
+        assert os.path.exists(os.path.join(str(work), "mr_sharded", "rank0_lane%d" % k, "clip.pt"))
