@@ -159,6 +159,16 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
             else while (upb % units_per_call) --units_per_call;
         }
     }
+    const bool per_batch_bias = bias && (size_t)rows_per_batch < (size_t)M;
+    if (per_batch_bias && units_per_call < units) {
+        // feasibility of every range BEFORE anything is launched: a range either starts on a batch boundary (and then holds
+        // whole entries or part of one) or lies inside one entry
+        for (size_t u0 = 0; u0 < units; u0 += units_per_call) {
+            const size_t out0 = u0 * out_rows_per_unit, rows = std::min(units_per_call, units - u0) * out_rows_per_unit;
+            const size_t in_entry = out0 % rows_per_batch;
+            if (in_entry && in_entry + rows > (size_t)rows_per_batch) return MC_ERR_UNSUPPORTED;
+        }
+    }
     for (size_t u0 = 0; u0 < units; u0 += units_per_call) {
         const size_t nu = std::min(units_per_call, units - u0);
         GemmParams q = p;
@@ -168,10 +178,10 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
         if (A2) q.A2 = p.A2 + in0 * lda2;
         q.C = p.C + out0 * ldc;
         if (R) q.R = p.R + out0 * ldr;
-        if (bias && (size_t)rows_per_batch < (size_t)M) {
+        if (per_batch_bias) {
             q.bias = bias + (out0 / rows_per_batch) * (size_t)N;
-            q.rows_per_batch = rows_per_batch;
-            if (out0 % rows_per_batch) return MC_ERR_UNSUPPORTED;
+            // inside one batch entry: a single bias row serves the whole range
+            q.rows_per_batch = (out0 % rows_per_batch) ? q.M : rows_per_batch;
         } else {
             q.rows_per_batch = q.M;
         }

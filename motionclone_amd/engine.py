@@ -72,7 +72,13 @@ class Weights:
 
     def _get(self, key, fn):
         if key not in self._c:
-            self._c[key] = fn()
+            t = fn()
+            # packed on whichever stream touches the weight first; lanes on OTHER streams look it up right after this returns,
+            # so the (cold-path) packing is completed before it is published.  Never reached under graph capture: the eager
+            # pass that precedes every capture has filled the cache.
+            if isinstance(t, torch.Tensor) and t.is_cuda and not torch.cuda.is_current_stream_capturing():
+                torch.cuda.current_stream(t.device).synchronize()
+            self._c[key] = t
         return self._c[key]
 
     def _h(self, t):
@@ -407,7 +413,7 @@ class UNet3DEngine:
                                       save_stats=tape is not None)
             qkv = ops.gemm(n, w.cat_lin([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]))
             del n
-            if record is not None:   # the guidance read-out sees the differentiated batch element only
+            if record is not None and self._hooked(aname):   # the guidance read-out sees the differentiated batch element only
                 rg, rcut = self._bslice(geo, tape.grad_batch if tape is not None else None)
                 record[aname] = dict(qkv=rcut(qkv), C=C, heads=heads, d=d, geo=rg)
             o = ops.tattn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], geo.B, geo.F, hw, heads, d)
@@ -448,7 +454,7 @@ class UNet3DEngine:
                 dh = ops.layernorm_bwd(dn, bh2, blsf, w.vec(b + "ff_norm.weight"), add=dh3)
             for a in reversed(range(n_attn)):
                 hin, ls, qkv, aname, ap = bsaved[a]
-                seed = seeds.get(aname) if seeds is not None else None
+                seed = seeds.get(aname) if seeds is not None and self._hooked(aname) else None
                 if dh is None and seed is None:
                     continue
                 da = ops.gemm(dh, w.lin_t(ap + "to_out.0.weight")) if dh is not None else None
@@ -521,8 +527,9 @@ class UNet3DEngine:
         tb_all = self._time_bias(t, B, latents)
         gb = self.guidance_block
 
-        def hook(nm):   # classify_blocks (util.py:434-440): substring match against every configured block
-            return any(blk in nm for blk in self.guidance_blocks)
+        def hook(nm):   # classify_blocks (util.py:434-440) matches the FULL attention-module names by substring: a motion
+            # module is hooked when any of its attentions is (entries longer than the module prefix included)
+            return any(self._hooked(nm + ".temporal_transformer.transformer_blocks.0.attention_blocks.%d" % a) for a in (0, 1))
 
         x_in = ops.latent_to_cl(latents, CIN_PAD)
         x = ops.gemm(x_in, w.conv("conv_in.weight", CIN_PAD), bias=w.vec("conv_in.bias").unsqueeze(0), mode=CONV_S1,
@@ -593,6 +600,9 @@ class UNet3DEngine:
         return eps
 
     # ---- guidance layer -----------------------------------------------------------------------------------
+    def _hooked(self, attention_name):
+        return any(blk in attention_name for blk in self.guidance_blocks)
+
     def hooked_names(self):
         """names of the hooked temporal attentions in module order (= the keys of the reference's .pt dict)"""
         L = self.cfg["layers_per_block"]

@@ -109,6 +109,12 @@ bias = torch.randn(4, N, generator=g); res = torch.randn(M, N, generator=g).half
 out = ops.gemm(a, w, bias=bias, residual=res, rows_per_batch=100)
 ref = a.float() @ w.float().t() + bias.repeat_interleave(100, 0) + res.float()
 assert (out.float() - ref).abs().max() < 3e-2, (out.float() - ref).abs().max()
+# the limit below ONE batch entry (200 rows x 256 B > 40 KiB): ranges of 100 rows lie inside an entry, the second range of
+# every entry starts off a batch boundary and takes that entry's bias row
+bias2 = torch.randn(2, N, generator=g)
+out2 = ops.gemm(a, w, bias=bias2, residual=res, rows_per_batch=200)
+ref2 = a.float() @ w.float().t() + bias2.repeat_interleave(200, 0) + res.float()
+assert (out2.float() - ref2).abs().max() < 3e-2, (out2.float() - ref2).abs().max()
 NF, C, H, W = 6, 64, 8, 8
 x = (torch.randn(NF, C, H, W, generator=g)).half(); wc = (torch.randn(72, C, 3, 3, generator=g) * 0.05).half()
 xc = x.permute(0, 2, 3, 1).reshape(-1, C).contiguous()
