@@ -18,7 +18,19 @@ _LOCAL = threading.local()
 
 def begin(lane, n_lanes, device):
     """mark the calling thread as lane `lane` of `n_lanes`; its serial-RNG stream lives on `device`"""
-    _LOCAL.lane, _LOCAL.n, _LOCAL.dev, _LOCAL.gen = lane, n_lanes, torch.device(device), None
+    _LOCAL.lane, _LOCAL.n, _LOCAL.dev, _LOCAL.gen, _LOCAL.warm = lane, n_lanes, torch.device(device), None, False
+
+
+def warmed_up():
+    """called by the launcher when the lane's first example is done: from here on the lanes run concurrently"""
+    _LOCAL.warm = True
+
+
+def may_capture():
+    """hipGraph capture is only done while a lane runs ALONE (its first example: the launcher serialises those).  ROCm 7.2
+    rejects synchronising calls of ANY host thread while a capture is open (hipErrorStreamCaptureUnsupported, also in
+    thread-local capture mode), so a step whose graph is missing once the lanes run concurrently is issued eagerly."""
+    return not active() or not getattr(_LOCAL, "warm", False)
 
 
 def end():

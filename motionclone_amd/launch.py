@@ -89,17 +89,30 @@ class _ShardedLines(io.StringIO):
     """file object over the examples file that yields only this rank's lines; before each of them it burns the global-RNG
     draws of the lines skipped since the previous one (see module docstring)"""
 
-    def __init__(self, lines, rank, world, burn):
+    def __init__(self, lines, rank, world, burn, first_begin=None, first_end=None):
         super().__init__("")
         self._items = [(i, ln) for i, ln in enumerate(lines) if ln.strip()]
         self._rank, self._world, self._burn = rank, world, burn
+        self._first_begin, self._first_end = first_begin, first_end     # lanes: the first example of a lane runs alone
 
     def __iter__(self):
-        for i, ln in self._items:
-            if i % self._world == self._rank:
-                yield ln
-            elif self._burn is not None:
-                self._burn(json.loads(ln))
+        n = 0
+        try:
+            for i, ln in self._items:
+                if i % self._world == self._rank:
+                    if n == 0 and self._first_begin:
+                        self._first_begin()
+                    if n == 1 and self._first_end:       # asked for the second line = the first example is finished
+                        self._first_end()
+                    n += 1
+                    yield ln
+                elif self._burn is not None:
+                    self._burn(json.loads(ln))
+        finally:
+            if n == 0 and self._first_begin:             # a lane without examples still takes its turn
+                self._first_begin()
+            if n <= 1 and self._first_end:
+                self._first_end()
 
 
 def main(argv=None):
@@ -170,8 +183,28 @@ def main(argv=None):
     def sharded_open(path, *a, **k):
         if sharded and isinstance(path, (str, os.PathLike)) and os.path.abspath(path) == ex_abs and (not a or "r" in a[0]):
             vrank = rank + world * (mcl.lane_index() or 0)
-            return _ShardedLines(lines, vrank, vworld, burn if serial_rng else None)
+            fb, fe = (warm_begin, warm_end) if n_lanes > 1 else (None, None)
+            return _ShardedLines(lines, vrank, vworld, burn if serial_rng else None, fb, fe)
         return real_open(path, *a, **k)
+
+    # A lane's FIRST example runs alone: it captures the lane's step graphs, and ROCm 7.2 rejects synchronising calls of any
+    # other host thread while a capture is open.  Turns are taken in lane order; when every lane has had its turn they all
+    # continue concurrently (replays only; lanes.may_capture).
+    warm_turn = threading.Condition()
+    warm_state = dict(turn=0)
+
+    def warm_begin():
+        with warm_turn:
+            warm_turn.wait_for(lambda: warm_state["turn"] == (mcl.lane_index() or 0))
+
+    def warm_end():
+        if on_gpu:
+            torch.cuda.current_stream().synchronize()
+        mcl.warmed_up()
+        with warm_turn:
+            warm_state["turn"] += 1
+            warm_turn.notify_all()
+            warm_turn.wait_for(lambda: warm_state["turn"] >= n_lanes)
 
     def lane_argv(lane):
         out = sargv

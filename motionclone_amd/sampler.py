@@ -3,10 +3,17 @@
 schedule_set_timesteps (:413-472) and schedule_customized_step (:285-409) folded into one fused
 CFG + DDIM kernel per step.  Host side is pure orchestration: per step it computes six scalars.
 """
+import threading
+
 import numpy as np
 import torch
 
 from . import ops
+
+# One hipGraph capture at a time per process: HIP refuses a capture_begin while another thread's capture is open
+# (hipErrorIllegalState on ROCm 7.2, also in thread-local capture mode).  The launcher additionally runs every lane's first
+# example - where all captures happen - alone (motionclone_amd/lanes.py).
+_CAPTURE_LOCK = threading.RLock()
 
 
 def ddim_alphas_cumprod(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012):
@@ -107,20 +114,24 @@ class MotionCloneSampler:
         key = (i, tuple(latents.shape), tuple(text.shape), rsig, csig, ops._GEMM_SHARE)   # the GEMM geometry is baked in
         ent = self._graphs.get(key)
         if ent is None:
-            s_lat, s_text = latents.clone(), text.clone()
-            s_rep = {k: tuple(t.clone() for t in v) for k, v in rep_dev.items()} if guided else {}
-            s_ctrl = None if ctrl is None else dict(cond=ctrl["cond"].clone(), mask=ctrl["mask"].clone(), scale=ctrl.get("scale", 1.0))
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):          # eager pass first: lazy one-time work (function attributes, caches)
-                first = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
-            torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            # thread_local: other host threads (launcher lanes) keep allocating / launching while this one captures
-            with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
-                s_out = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
-            if self._graph_pool is None:
-                self._graph_pool = graph.pool()
+            from . import lanes
+            if not lanes.may_capture():
+                return None      # lanes already run concurrently: no capture now (lanes.may_capture), the caller goes eager
+            with _CAPTURE_LOCK:
+                s_lat, s_text = latents.clone(), text.clone()
+                s_rep = {k: tuple(t.clone() for t in v) for k, v in rep_dev.items()} if guided else {}
+                s_ctrl = None if ctrl is None else dict(cond=ctrl["cond"].clone(), mask=ctrl["mask"].clone(), scale=ctrl.get("scale", 1.0))
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):          # eager pass first: lazy one-time work (function attributes, caches)
+                    first = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
+                torch.cuda.current_stream().wait_stream(side)
+                graph = torch.cuda.CUDAGraph()
+                # thread_local: other host threads (launcher lanes) keep allocating / launching while this one captures
+                with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
+                    s_out = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
+                if self._graph_pool is None:
+                    self._graph_pool = graph.pool()
             self._graphs[key] = (graph, s_lat, s_text, s_rep, s_ctrl, s_out)
             return first
         graph, s_lat, s_text, s_rep, s_ctrl, s_out = ent
@@ -157,7 +168,9 @@ class MotionCloneSampler:
             ops.add(flat, variance_noise.to(prev.dtype).contiguous().reshape(flat.shape), out=flat, sa=1.0, sb=sigma)
             return prev
         if self._graphs is not None and aux is None and latents.is_cuda:
-            return self._graphed_step(latents, i, text, rep_dev, ctrl)
+            out = self._graphed_step(latents, i, text, rep_dev, ctrl)
+            if out is not None:
+                return out
         return self._step_eager(latents, i, text, rep_dev, aux, ctrl)
 
     @ops.scoped

@@ -48,8 +48,15 @@ def _sampler(pipe):
     the reference API runs the same path bench.py times."""
     c = pipe.input_config
     sch = pipe.scheduler
-    ts = tuple(int(t) for t in torch.as_tensor(sch.timesteps).cpu().tolist())
-    acp = torch.as_tensor(sch.alphas_cumprod).detach().float().cpu()
+    # reading the scheduler's tables is a device -> host copy: done again only when the scheduler's tensors were replaced or
+    # written (customized_set_timesteps assigns a new tensor), not on every step
+    tkey = (id(sch.timesteps), getattr(sch.timesteps, "_version", 0), id(sch.alphas_cumprod),
+            getattr(sch.alphas_cumprod, "_version", 0))
+    if getattr(pipe, "_mc_sched_key", None) != tkey:
+        pipe._mc_sched_tables = (tuple(int(t) for t in torch.as_tensor(sch.timesteps).cpu().tolist()),
+                                 torch.as_tensor(sch.alphas_cumprod).detach().float().cpu())
+        pipe._mc_sched_key = tkey
+    ts, acp = pipe._mc_sched_tables
     final = float(getattr(sch, "final_alpha_cumprod", 1.0))
     if len(ts) != int(c.inference_steps):
         raise ValueError("scheduler holds %d timesteps but input_config.inference_steps = %d: run "

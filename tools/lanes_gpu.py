@@ -93,6 +93,8 @@ def run(n_lanes, n_videos, sd, results, share):
         ts = [threading.Thread(target=lane, args=(k, timed)) for k in range(n_lanes)]
         for t in ts:
             t.start()
+            if not timed:
+                t.join()      # warm-up: one lane at a time (all hipGraph captures happen here, lanes.may_capture)
         for t in ts:
             t.join()
         if errors:
