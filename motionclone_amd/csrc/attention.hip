@@ -28,7 +28,34 @@ struct AParams {
     int Nq, Nk, heads, d, nbatch, kv_bdiv;
     float scale;
     int causal;   // forward only: key j attends to query i iff j <= i (CLIP text encoder); 0 on the UNet path
+    int xcd_map;  // 1: 1-D grid, all row blocks of one (batch, head) on ONE XCD (attn_block); 0: grid (row blocks, heads, batch)
 };
+
+// Which (row block, head, batch element) this workgroup owns.  With the plain 3-D grid consecutive workgroups are the row
+// blocks of ONE (batch, head) and the hardware deals them round-robin over the 8 XCDs, so every XCD's L2 fetches every K / V
+// tile of every head (8x the fill traffic; the 16 row blocks of a level-0 head share 655 KB of K / V).  Here workgroup
+// `pid` (on XCD pid % 8, a speed assumption only) takes unit u = (local / nxb) * 8 + xcd: all nxb row blocks of a unit run on
+// the same XCD back to back and meet in its L2.
+__device__ __forceinline__ bool attn_block(const AParams& P, int nxb, int& xb, int& h, int& b) {
+    if (!P.xcd_map) {
+        xb = blockIdx.x;
+        h = blockIdx.y;
+        b = blockIdx.z;
+        return true;
+    }
+    const int pid = blockIdx.x, xcd = pid & 7, local = pid >> 3;
+    const int u = (local / nxb) * 8 + xcd;
+    xb = local - (local / nxb) * nxb;
+    if (u >= P.heads * P.nbatch) return false;
+    h = u % P.heads;
+    b = u / P.heads;
+    return true;
+}
+static inline dim3 attn_grid(const AParams& P, int nxb) {
+    if (!P.xcd_map) return dim3((unsigned)nxb, (unsigned)P.heads, (unsigned)P.nbatch);
+    const int units = P.heads * P.nbatch;
+    return dim3((unsigned)(((units + 7) / 8) * 8 * nxb));
+}
 
 constexpr int KV_TILE = 64;
 constexpr int TPAD = 72;  // row length (halfs) of transposed tiles: 64 + 8
@@ -107,10 +134,11 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
     half_t* Vt0 = Ks0 + NB * KS_HALFS;                  // [NB][DT*16][TPAD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c15 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int xb, h, b;
+    if (!attn_block(P, (P.Nq + 64 * QT - 1) / (64 * QT), xb, h, b)) return;
     const int col0 = h * P.d;
     const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)(b / P.kv_bdiv) * P.Nk;
-    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int q0 = xb * (64 * QT) + wave * (16 * QT);
     const int vpr = P.d / 8;
     const float sl2 = P.scale * 1.4426950408889634f;  // scores are carried in log2 units
 
@@ -353,6 +381,242 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
     }
 }
 
+// ---- forward, long sequences: K / V through an LDS-DMA ring ------------------------------------------------------------
+// Same arithmetic as attn_fwd_kernel (S^T = K Q^T tile by tile, online softmax in the exp2 domain, P^T as the B operand of the
+// PV MFMAs straight from the accumulators); what differs is everything around the MFMAs:
+//   * K and V tiles (64 keys) arrive by LDS-DMA (buffer_load ... lds) into a ring of three stages, two tiles ahead of their
+//     use: no staging registers, no VALU, no exposed load latency, ONE bare barrier per tile (the old loop had two, with the
+//     global load between them);
+//   * both images are row-major [64][32 DT bytes].  K fragments are 16-byte reads (the contraction index is permuted so a lane's
+//     8 k-slots are 8 adjacent head-dim elements; chunks of rows 8..15 of every 16 are swapped pairwise, which makes the reads
+//     conflict-free); V^T fragments come from the SAME row-major layout through the hardware transpose read
+//     (ds_read_b64_tr_b16; the 24 / 40-dword pitch is conflict-free for it) - the register transpose and its packed writes are gone;
+//   * head-dim padding is hardware zero fill: the chunk [d, 16 DT) of every row is fetched out of range.  At d = 40 the ones row
+//     that makes the PV MFMAs produce the softmax denominators is OR-ed into the one lane's V^T fragment that holds row d;
+//   * the 16-wide remainder of the head dim (d = 40: 8 live + 8 zero; d = 80: 16) runs as ONE v_mfma_f32_16x16x16_f16 issued
+//     FIRST on a zero accumulator, the 32-wide steps accumulate on top (4 independent MFMAs later): 24 instead of 32 MFMA
+//     cycles per 16 x 16 scores at d = 40;
+//   * the softmax's cross-row max is two VALU lane swaps (rows_max), not two ds_bpermute round trips;
+//   * per query tile the order is softmax(t) -> PV(t), so the VALU of tile t + 1 issues under the MFMAs of tile t.
+template <int DT, int QT, bool LEG>
+__global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t* o, int ldo, float* lse) {
+    constexpr int CPR = 2 * DT;          // 16-byte chunks per image row
+    constexpr int PB = 32 * DT;          // row pitch, bytes
+    constexpr int IMG = KV_TILE * PB;    // one matrix of one stage
+    constexpr int STAGE = 2 * IMG;
+    constexpr int NSTG = 3;
+    constexpr int IPW = 2 * CPR / 4;     // LDS-DMA instructions per wave and tile (K + V = 2 CPR KiB over 4 waves)
+    constexpr int NMAIN = DT / 2;        // 32-wide steps of the head dim
+    constexpr bool ODD = DT & 1;         // a 16-wide remainder
+    static_assert((2 * CPR) % 4 == 0, "stage must split evenly over the four waves");
+    MC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63;
+#ifdef MC_EMU
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // provably uniform: K / V descriptor choice is scalar
+#endif
+    const int g = lane >> 4, c15 = lane & 15;
+    int xb, h, b;
+    if (!attn_block(P, (P.Nq + 64 * QT - 1) / (64 * QT), xb, h, b)) return;
+    const int col0 = h * P.d;
+    const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)(b / P.kv_bdiv) * P.Nk;
+    const int q0 = xb * (64 * QT) + wave * (16 * QT);
+    const int vpr = P.d / 8;
+    const float sl2 = P.scale * 1.4426950408889634f;
+    const bool ones_row = P.d < DT * 16;
+    const int nk = (P.Nk + KV_TILE - 1) / KV_TILE;
+
+    // ---- LDS-DMA slots of this lane: instruction n = wave + 4 i fills chunks [64 (n % CPR), +64) of K (n < CPR) or V
+    const GBuf kbuf = make_gbuf(P.k + kbase * P.ldk, (uint32_t)P.Nk * P.ldk * 2);
+    const GBuf vbuf = make_gbuf(P.v + kbase * P.ldv, (uint32_t)P.Nk * P.ldv * 2);
+    uint32_t dma_off[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int n = wave + 4 * i;
+        const bool is_v = n >= CPR;
+        const int pch = (n % CPR) * 64 + lane;        // chunk position inside the image
+        const int row = pch / CPR, cp = pch % CPR;
+        const int c = is_v ? cp : (cp ^ ((row >> 3) & 1));
+        const int ld = is_v ? P.ldv : P.ldk;
+        dma_off[i] = c < vpr ? (uint32_t)(row * ld + col0 + 8 * c) * 2 : kOOB;
+    }
+    auto issue = [&](int tile) {
+        char* stg = smem + (tile % NSTG) * STAGE;
+        const uint32_t ko = (uint32_t)tile * KV_TILE * P.ldk * 2, vo = (uint32_t)tile * KV_TILE * P.ldv * 2;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int n = wave + 4 * i;
+            if (n >= CPR) glds16(vbuf, dma_off[i] + vo, stg + IMG + (n - CPR) * 1024);
+            else glds16(kbuf, dma_off[i] + ko, stg + n * 1024);
+        }
+    };
+    // ---- Q fragments (B operand): 32-wide step s holds head-dim [32 s + 8 g, +8), the remainder [32 NMAIN + 4 g, +4)
+    half8_t qm[QT][NMAIN > 0 ? NMAIN : 1];
+    half4_t qr[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + 16 * t + c15;
+        const half_t* qp = P.q + (qbase + qi) * P.ldq + col0;
+#pragma unroll
+        for (int s2 = 0; s2 < NMAIN; ++s2) qm[t][s2] = qi < P.Nq ? ld8(qp + 32 * s2 + 8 * g) : zero8();
+        if (ODD) qr[t] = (qi < P.Nq && 32 * NMAIN + 4 * g < P.d) ? ld4(qp + 32 * NMAIN + 4 * g) : zero4();
+    }
+    issue(0);
+    if (nk > 1) issue(1);
+#ifndef MC_EMU
+    // a use of the Q registers HERE: hipcc then waits for the Q loads (older than the two tiles in flight, so a counted wait)
+    // in front of the loop instead of putting a vmcnt(0) - which would also drain the LDS-DMA ring - before the loop's first MFMA
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+#pragma unroll
+        for (int s2 = 0; s2 < NMAIN; ++s2) asm volatile("" ::"v"(qm[t][s2]));
+        if (ODD) asm volatile("" ::"v"(qr[t]));
+    }
+#endif
+    f32x4 oacc[QT][DT];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY;
+        l[t] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) oacc[t][dt] = fzero4();
+    }
+    // per-lane read bases inside a stage (bytes)
+    const int swz = (c15 >> 3) & 1;
+    const int k_main = c15 * PB + ((g ^ swz) << 4);
+    const int k_rem = c15 * PB + ((4 * NMAIN + ((g >> 1) ^ swz)) << 4) + 8 * (g & 1);
+    const int v_tr = IMG + (4 * g + (c15 >> 2)) * PB + 8 * (c15 & 3);
+    // the lane of the last V^T fragment that holds row d (= softmax denominators): fp16 1.0 in all its k-slots
+    const uint32_t ones_bits = (ones_row && c15 == (P.d & 15)) ? 0x3C003C00u : 0u;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        // my part of tile kt has landed (the younger tile may still be in flight); behind the barrier everyone's has, and
+        // every wave is done reading tile kt - 1, whose stage tile kt + 2 overwrites
+        if (kt + 1 < nk) wait_vmcnt_le<IPW>();
+        else wait_vmcnt_le<0>();
+        raw_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const char* stg = smem + (kt % NSTG) * STAGE;
+        const int kv0 = kt * KV_TILE;
+
+        f32x4 st[QT][4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const char* kj = stg + j * 16 * PB;
+            if (ODD && LEG) {
+                const half4_t kr = ld4(reinterpret_cast<const half_t*>(kj + k_rem));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) st[t][j] = mfma16(kr, qr[t], fzero4());
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < NMAIN; ++s2) {
+                const half8_t kf = ld8(reinterpret_cast<const half_t*>(kj + k_main + 64 * s2));
+#pragma unroll
+                for (int t = 0; t < QT; ++t)
+                    st[t][j] = mfma16k32(kf, qm[t][s2], ((!ODD || !LEG) && s2 == 0) ? fzero4() : st[t][j]);
+            }
+            if (ODD && !LEG) {   // A/B form: the remainder as a zero-extended 32-wide step behind the others
+                const half8_t kr = cat4(ld4(reinterpret_cast<const half_t*>(kj + k_rem)), zero4());
+#pragma unroll
+                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kr, cat4(qr[t], zero4()), NMAIN == 0 ? fzero4() : st[t][j]);
+            }
+        }
+        // V^T fragments of the whole tile: [dt][jp] = keys {32 jp + 4 g + e, 32 jp + 16 + 4 g + e} x head-dim 16 dt + c15
+        // (issued now, awaited in front of the first PV MFMA: the first query tile's softmax covers their latency)
+        half8_t vf[DT][2];
+        static_for<DT>([&](auto dt_) {
+            constexpr int dt = decltype(dt_)::value;
+            vf[dt][0] = cat4(lds_read_tr4_async<32 * dt>(stg + v_tr), lds_read_tr4_async<32 * dt + 16 * PB>(stg + v_tr));
+            vf[dt][1] = cat4(lds_read_tr4_async<32 * dt + 32 * PB>(stg + v_tr), lds_read_tr4_async<32 * dt + 48 * PB>(stg + v_tr));
+        });
+        const bool tail = kv0 + KV_TILE > P.Nk;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            if (tail) {   // wave-uniform; live keys of this lane group are 16 j + i < Nk - kv0 - 4 g (constants against one value)
+                const int live = opaque(P.Nk - kv0 - 4 * g);
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (16 * j + i >= live) st[t][j][i] = -INFINITY;
+            }
+            float mx = max3(st[t][0][0], st[t][0][1], st[t][0][2]);
+            mx = max3(mx, st[t][0][3], st[t][1][0]);
+            mx = max3(mx, st[t][1][1], st[t][1][2]);
+            mx = max3(mx, st[t][1][3], st[t][2][0]);
+            mx = max3(mx, st[t][2][1], st[t][2][2]);
+            mx = max3(mx, st[t][2][3], st[t][3][0]);
+            mx = max3(mx, st[t][3][1], st[t][3][2]);
+            mx = fmaxf(mx, st[t][3][3]);
+            mx = rows_max(mx);
+            const float mnew = fmaxf(m[t], mx * sl2);
+            float rs = 0.f;
+            half8_t pf[2];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; i += 2) {
+                    const float e0 = fast_exp2(fmaf(st[t][j][i], sl2, -mnew));
+                    const float e1 = fast_exp2(fmaf(st[t][j][i + 1], sl2, -mnew));
+                    if (!ones_row) rs += e0 + e1;
+                    const half2_t h2 = pk_rtz(e0, e1);
+                    pf[j >> 1][4 * (j & 1) + i] = h2[0];
+                    pf[j >> 1][4 * (j & 1) + i + 1] = h2[1];
+                }
+            if (!ones_row) rs = rows_sum(rs);
+            // the output rescale only when a running max moved (rare after the first tiles), in place
+            const float alpha = fast_exp2(m[t] - mnew);   // m = mnew = -inf cannot happen: a tile always holds a live key
+            l[t] = l[t] * alpha + rs;
+            if (!wave_all(mnew == m[t])) {
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) scale_in_place(oacc[t][dt], alpha);
+            }
+            m[t] = mnew;
+            if (t == 0) {
+                lds_tr_wait();
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) lds_tr_use(vf[dt][jp]);
+                if (ones_row) {
+#pragma unroll
+                    for (int jp = 0; jp < 2; ++jp) {
+                        u32x4 w = __builtin_bit_cast(u32x4, vf[DT - 1][jp]);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) w[i] |= ones_bits;
+                        vf[DT - 1][jp] = __builtin_bit_cast(half8_t, w);
+                    }
+                }
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) oacc[t][dt] = mfma16k32(vf[dt][jp], pf[jp], oacc[t][dt]);
+        }
+    }
+
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + 16 * t + c15;
+        const float lt = ones_row ? shfl(oacc[t][DT - 1][0], 16 * ((P.d & 15) >> 2) + c15) : l[t];
+        if (qi >= P.Nq) continue;
+        const float inv = 1.0f / lt;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = 16 * dt + 4 * g;
+            if (c < P.d) {
+                half4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = to_half(oacc[t][dt][i] * inv);
+                st4(o + (qbase + qi) * ldo + col0 + c, ov);
+            }
+        }
+        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = (m[t] + log2f(lt)) * 0.6931471805599453f;
+    }
+}
+
 // ---- backward: dQ (and D = rowsum(dO * O)) ---------------------------------------------------
 // QT query tiles (16 rows each) per wave: every K / V / K^T fragment read from LDS feeds QT MFMAs, and a block's
 // staged tile serves 64*QT query rows.
@@ -368,10 +632,11 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 5) ? 4 : 2) void attn_bwd_dq
     half_t* Kt = Vs + KV_TILE * RP;                // [DT*16][TPAD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c15 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int xb, h, b;
+    if (!attn_block(P, (P.Nq + 64 * QT - 1) / (64 * QT), xb, h, b)) return;
     const int col0 = h * P.d;
     const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)(b / P.kv_bdiv) * P.Nk;
-    const int q0 = blockIdx.x * (64 * QT) + wave * (16 * QT);
+    const int q0 = xb * (64 * QT) + wave * (16 * QT);
     const float sl2 = P.scale * 1.4426950408889634f;
 
     zero_pads<DT>(Ks, Kt, P.d);
@@ -500,10 +765,11 @@ __global__ __launch_bounds__(256, (KT == 1 && DT <= 4) ? 4 : ((KT == 1 && DT == 
     float* D_s = lse_s + KV_TILE;                                   // [64]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int g = lane >> 4, c15 = lane & 15;
-    const int h = blockIdx.y, b = blockIdx.z;
+    int xb, h, b;
+    if (!attn_block(P, (P.Nk + 64 * KT - 1) / (64 * KT), xb, h, b)) return;
     const int col0 = h * P.d;
     const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)b * P.Nk;
-    const int k0 = blockIdx.x * (64 * KT) + wave * (16 * KT);
+    const int k0 = xb * (64 * KT) + wave * (16 * KT);
     const float sl2 = P.scale * 1.4426950408889634f;
 
     zero_pads<DT>(Qs, Qt, P.d);
@@ -631,7 +897,7 @@ static void a_launch_fwd_cfg(const AParams& P, half_t* o, int ldo, float* lse, h
     constexpr int RP = DT * 16 + 8;
     size_t smem = (size_t)(PF ? 2 : 1) * (KV_TILE * RP + DT * 16 * TPAD) * sizeof(half_t);
     allow_big_smem(attn_fwd_kernel<DT, QT, PF>, smem);
-    dim3 grid((P.Nq + 64 * QT - 1) / (64 * QT), P.heads, P.nbatch);
+    dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
     MC_LAUNCH((attn_fwd_kernel<DT, QT, PF>), grid, dim3(256), smem, s, P, o, ldo, lse);
 }
 
@@ -639,10 +905,39 @@ static void a_launch_fwd_cfg(const AParams& P, half_t* o, int ldo, float* lse, h
 // (profiles/r01_attention_config_sweep.txt): two query tiles per wave win at every level (half the LDS traffic per
 // query); the register prefetch never pays - the loop is VALU-bound on the softmax and occupancy matters more.
 // MC_ATTN_QT / MC_ATTN_PF override the choice for experiments.
+template <int DT, int QT, bool LEG>
+static void a_launch_fwd_ring(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
+    size_t smem = (size_t)3 * 2 * KV_TILE * 32 * DT;
+    allow_big_smem(attn_fwd_ring_kernel<DT, QT, LEG>, smem);
+    dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
+    MC_LAUNCH((attn_fwd_ring_kernel<DT, QT, LEG>), grid, dim3(256), smem, s, P, o, ldo, lse);
+}
+
+// MC_ATTN_RING: 0 = never the LDS-DMA ring kernel, 2 = at every size it supports (tests), default = long sequences
+static int attn_ring_env() {
+#ifdef MC_EMU
+    return getenv("MC_ATTN_RING") ? atoi(getenv("MC_ATTN_RING")) : 1;   // re-read per call: the tests flip it
+#else
+    static const int v = getenv("MC_ATTN_RING") ? atoi(getenv("MC_ATTN_RING")) : 1;
+    return v;
+#endif
+}
+
 template <int DT>
 static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
     static const int qt_env = getenv("MC_ATTN_QT") ? atoi(getenv("MC_ATTN_QT")) : 0;
     static const int pf_env = getenv("MC_ATTN_PF") ? atoi(getenv("MC_ATTN_PF")) : -1;
+    if constexpr (DT == 3) {
+        const int ring = attn_ring_env();
+        if (!P.causal && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512))) {
+            // remainder step: the 16-wide legacy MFMA passes every test and measures 0.6-1.2 % faster (the loop is VALU-bound),
+            // but mixed MFMA shapes on one accumulator have returned wrong sums on gfx950 before - not worth it
+            static const int leg_env = getenv("MC_ATTN_LEG") ? atoi(getenv("MC_ATTN_LEG")) : 0;
+            if (leg_env) a_launch_fwd_ring<DT, 4, true>(P, o, ldo, lse, s);
+            else a_launch_fwd_ring<DT, 4, false>(P, o, ldo, lse, s);
+            return;
+        }
+    }
     bool two = qt_env ? qt_env == 2 : P.Nq >= 256;
     bool pf = pf_env >= 0 ? pf_env != 0 : false;
     if constexpr (DT == 3) {
@@ -666,7 +961,7 @@ static void a_launch_dq_cfg(const AParams& P, const half_t* o, int ldo, const ha
                             float* Dbuf, half_t* dq, int lddq, hipStream_t s) {
     constexpr int RP = DT * 16 + 8;
     size_t smem = (size_t)(2 * KV_TILE * RP + DT * 16 * TPAD) * sizeof(half_t);
-    dim3 grid((P.Nq + 64 * QT - 1) / (64 * QT), P.heads, P.nbatch);
+    dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
     allow_big_smem(attn_bwd_dq_kernel<DT, QT>, smem);
     MC_LAUNCH((attn_bwd_dq_kernel<DT, QT>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
 }
@@ -675,7 +970,7 @@ static void a_launch_dkdv_cfg(const AParams& P, const half_t* dO, int lddo, cons
                               half_t* dk, int lddk, half_t* dv, int lddv, hipStream_t s) {
     constexpr int RP = DT * 16 + 8;
     size_t smem = (size_t)(2 * KV_TILE * RP + 2 * DT * 16 * TPAD) * sizeof(half_t) + 2 * KV_TILE * sizeof(float);
-    dim3 grid((P.Nk + 64 * KT - 1) / (64 * KT), P.heads, P.nbatch);
+    dim3 grid = attn_grid(P, (P.Nk + 64 * KT - 1) / (64 * KT));
     allow_big_smem(attn_bwd_dkdv_kernel<DT, KT>, smem);
     MC_LAUNCH((attn_bwd_dkdv_kernel<DT, KT>), grid, dim3(256), smem, s, P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv);
 }
@@ -733,6 +1028,14 @@ static AParams a_params(const void* q, const void* k, const void* v, int ldq, in
     P.q = (const half_t*)q; P.k = (const half_t*)k; P.v = (const half_t*)v;
     P.ldq = ldq; P.ldk = ldk; P.ldv = ldv; P.Nq = Nq; P.Nk = Nk; P.heads = heads; P.d = d;
     P.nbatch = nbatch; P.kv_bdiv = kv_bdiv; P.scale = scale; P.causal = 0;
+    // one (batch, head) per XCD at a time pays when several row blocks share a K / V worth caching and there are units for all
+    // 8 XCDs; MC_ATTN_XCD=0 restores the plain grid (A/B), 2 takes the mapping at every size (tests)
+#ifdef MC_EMU
+    const int xcd_env = getenv("MC_ATTN_XCD") ? atoi(getenv("MC_ATTN_XCD")) : 1;   // re-read per call: the tests flip it
+#else
+    static const int xcd_env = getenv("MC_ATTN_XCD") ? atoi(getenv("MC_ATTN_XCD")) : 1;
+#endif
+    P.xcd_map = xcd_env == 2 || (xcd_env && heads * nbatch >= 8 && Nq >= 512 && Nk >= 512);
     return P;
 }
 

@@ -15,6 +15,7 @@
 #endif
 #include <stdint.h>
 #include <algorithm>
+#include <type_traits>
 #include <cmath>
 #include <cstdio>
 
@@ -202,6 +203,101 @@ __device__ inline float fast_exp2(float x) { return exp2f(x); }
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
+
+// hardware transpose read (ds_read_b64_tr_b16): within each 16-lane group lane i passes the address of halfs [4 (i & 3), +4)
+// of row i >> 2 of a 4 x 16 block (any row pitch, 8-byte aligned) and receives column i of the block, rows 0..3 - a
+// column of a row-major LDS image as an MFMA operand without a transposed copy
+#ifdef MC_EMU
+__device__ inline half4_t lds_read_tr4(const half_t* p) { return hipemu::lds_read_tr16_b64(p); }
+#else
+__device__ __forceinline__ half4_t lds_read_tr4(const half_t* p) {
+    typedef __fp16 fp16x4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+    return __builtin_bit_cast(half4_t, __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) fp16x4*)p));
+}
+#endif
+// The same read issued BEHIND THE COMPILER'S BACK (inline asm; `base` + OFF bytes): hipcc puts an s_waitcnt vmcnt(0) in front of
+// the builtin form whenever an LDS-DMA load is in flight (it cannot tell the images apart), which drains a prefetch ring.  The
+// result may only be used after lds_tr_wait() and a lds_tr_use() on the value.
+#ifdef MC_EMU
+template <int OFF>
+__device__ inline half4_t lds_read_tr4_async(const char* base) {
+    return hipemu::lds_read_tr16_b64(base + OFF);
+}
+__device__ inline void lds_tr_wait() {}
+__device__ inline void lds_tr_use(half8_t&) {}
+#else
+template <int OFF>
+__device__ __forceinline__ half4_t lds_read_tr4_async(const char* base) {
+    half4_t r;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)base;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(r) : "v"(a), "n"(OFF));
+    return r;
+}
+__device__ __forceinline__ void lds_tr_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void lds_tr_use(half8_t& v) { asm volatile("" : "+v"(v)); }   // orders the uses behind the wait
+#endif
+// max / sum over the four 16-lane rows of a wave (lanes l, l^16, l^32, l^48), every lane gets the result: two VALU lane swaps
+// (v_permlane16_swap, v_permlane32_swap) instead of two LDS round trips (ds_bpermute)
+#ifdef MC_EMU
+__device__ inline float rows_max(float v) {
+    unsigned x = __builtin_bit_cast(unsigned, v);
+    auto r = hipemu::permlane_swap(x, x, 16);
+    v = fmaxf(__builtin_bit_cast(float, r.a), __builtin_bit_cast(float, r.b));
+    x = __builtin_bit_cast(unsigned, v);
+    r = hipemu::permlane_swap(x, x, 32);
+    return fmaxf(__builtin_bit_cast(float, r.a), __builtin_bit_cast(float, r.b));
+}
+__device__ inline void scale_in_place(f32x4& x, float a) { x *= a; }
+__device__ inline float rows_sum(float v) {
+    unsigned x = __builtin_bit_cast(unsigned, v);
+    auto r = hipemu::permlane_swap(x, x, 16);
+    v = __builtin_bit_cast(float, r.a) + __builtin_bit_cast(float, r.b);
+    x = __builtin_bit_cast(unsigned, v);
+    r = hipemu::permlane_swap(x, x, 32);
+    return __builtin_bit_cast(float, r.a) + __builtin_bit_cast(float, r.b);
+}
+#else
+__device__ __forceinline__ float rows_max(float v) {
+    // (inline v_max: fmaxf on a bit-cast value costs a canonicalising v_max per operand)
+    unsigned x = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    float m;
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    x = __builtin_bit_cast(unsigned, m);
+    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
+}
+__device__ __forceinline__ float rows_sum(float v) {
+    // (inline v_add as well: hipcc folded r[0] + r[1] of the swap builtin into 2 * r[0])
+    unsigned x = __builtin_bit_cast(unsigned, v);
+    auto r = __builtin_amdgcn_permlane16_swap(x, x, false, false);
+    float m;
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    x = __builtin_bit_cast(unsigned, m);
+    r = __builtin_amdgcn_permlane32_swap(x, x, false, false);
+    asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
+    return m;
+}
+// x *= a in place (a tied inline v_mul): inside a rarely taken branch this keeps the untouched path free of register copies
+__device__ __forceinline__ void scale_in_place(f32x4& x, float a) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float e = x[i];
+        asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e) : "v"(a));
+        x[i] = e;
+    }
+}
+#endif
+
+// f(integral_constant<int, 0>) ... f(integral_constant<int, N - 1>): a loop whose index is a compile-time constant in the body
+template <int N, int I = 0, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<N, I + 1>(f);
+    }
+}
 
 // reductions across the 64 lanes of a wave
 __device__ inline float wave_sum(float v) {

@@ -196,6 +196,35 @@ inline f16v mfma_32x32x16(h8 a, h8 b, f16v c) {
     return c;
 }
 
+// ds_read_b64_tr_b16: within each 16-lane group lane i supplies the address of 4 contiguous 16-bit elements - columns
+// [4 (i & 3), +4) of row i >> 2 of a 4 x 16 block - and receives column i of that block (rows 0..3).
+inline h4 lds_read_tr16_b64(const void* p) {
+    auto buf = exchange(&p, sizeof(p));
+    int l = lane_id();
+    int base = l & ~15, i = l & 15;
+    h4 r;
+    for (int j = 0; j < 4; ++j) {
+        const void* src;
+        std::memcpy(&src, buf[base + 4 * j + (i >> 2)], sizeof(src));
+        r[j] = reinterpret_cast<const _Float16*>(src)[i & 3];
+    }
+    return r;
+}
+
+// v_permlane16_swap_b32 / v_permlane32_swap_b32 (rows = 16 lanes): the odd rows of `a` trade places with the even rows of `b`
+// (16), the upper 32 lanes of `a` with the lower 32 lanes of `b` (32).  Returns the new (a, b).
+struct u2 { unsigned a, b; };
+inline u2 permlane_swap(unsigned a, unsigned b, int width) {
+    u2 mine{a, b};
+    auto buf = exchange(&mine, sizeof(mine));
+    int l = lane_id();
+    bool first_half = width == 16 ? ((l >> 4) & 1) == 0 : l < 32;
+    u2 other;
+    std::memcpy(&other, buf[l ^ width], sizeof(other));
+    // lanes in the "even" half: a keeps, b receives the partner's a; lanes in the "odd" half: a receives the partner's b
+    return first_half ? u2{a, other.a} : u2{other.b, b};
+}
+
 void run_block(BlockCtx& ctx, char* stacks);
 
 template <class F>

@@ -409,6 +409,66 @@ def test_self_attention_long_sequence_takes_four_query_tiles_per_wave(backend):
     close(_heads(dqkv[:, 2 * C:], nb, Nq, heads, d), gv, 1e-2, 2e-2, "attn dv, 4 tiles per wave")
 
 
+def test_attention_xcd_block_mapping_is_the_same_arithmetic(backend, monkeypatch):
+    """attention.hip attn_block: the 1-D launch that keeps all row blocks of one (batch, head) on one XCD only renames
+    workgroups, so forward and backward are bit-identical to the plain (row block, head, batch) grid - also when the number
+    of (batch, head) units is not a multiple of the 8 XCDs.  On the emulator MC_ATTN_XCD is re-read per call; on the GPU the
+    default already takes the mapping at this size and the comparison is against the oracle-checked tests above."""
+    dev = backend
+    if big(dev):
+        d, Nq, heads, nb = 40, 1024 + 19, 3, 3
+    else:
+        d, Nq, heads, nb = 16, 150, 3, 3
+    C = heads * d
+    qkv = rnd((nb * Nq, 3 * C), dev, 11, 0.7)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    do = rnd((nb * Nq, C), dev, 12)
+
+    def run():
+        o, lse = ops.attn_fwd(q, k, v, Nq, Nq, heads, d, nb)
+        dqkv = torch.zeros_like(qkv)
+        ops.attn_bwd(q, k, v, o, do, lse, Nq, Nq, heads, d, nb, dq=dqkv[:, :C], dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:])
+        return o, lse, dqkv
+
+    monkeypatch.setenv("MC_ATTN_XCD", "0")
+    plain = run()
+    monkeypatch.setenv("MC_ATTN_XCD", "2")
+    mapped = run()
+    for a, b, what in zip(plain, mapped, ("o", "lse", "dqkv")):
+        assert torch.equal(a, b), "attention %s differs between the plain grid and the XCD mapping" % what
+    Q, K, V = (_heads(t, nb, Nq, heads, d) for t in (q, k, v))
+    close(_heads(mapped[0], nb, Nq, heads, d), ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ V, 1e-2, 1e-2, "attn fwd, XCD mapping")
+
+
+@pytest.mark.parametrize("Nq,Nk,share", [(150, 150, 1), (70, 64, 1), (300, 77, 3), (64, 333, 1)])
+def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share):
+    """attention.hip attn_fwd_ring_kernel (d = 40 long sequences: LDS-DMA ring, transpose reads, 16-wide remainder step first):
+    one / several / ragged key tiles, ragged query blocks, keys shared by `share` batch entries.  On the emulator the kernel
+    is forced at these small sizes (MC_ATTN_RING is re-read per call) and compared with the register-staged kernel as well;
+    on the GPU the sizes are the ones that select it by default."""
+    dev = backend
+    heads, d, nb = 2, 40, 2 * share
+    if big(dev):
+        Nq, Nk, heads = Nq * 8 + 5, (Nk * 8 + 3 if Nk != 77 else 77 * 8), 8
+    C = heads * d
+    q = rnd((nb * Nq, C), dev, 21, 0.7)
+    kv = rnd((nb // share * Nk, 2 * C), dev, 22, 0.7)
+    k, v = kv[:, :C], kv[:, C:]
+    monkeypatch.setenv("MC_ATTN_RING", "2")
+    o, lse = ops.attn_fwd(q, k, v, Nq, Nk, heads, d, nb, kv_bdiv=share)
+    Q = _heads(q, nb, Nq, heads, d)
+    K = _heads(k, nb // share, Nk, heads, d).repeat_interleave(share, 0)
+    V = _heads(v, nb // share, Nk, heads, d).repeat_interleave(share, 0)
+    S = (Q @ K.transpose(-1, -2)) * d ** -0.5
+    close(_heads(o, nb, Nq, heads, d), S.softmax(-1) @ V, 1e-2, 1e-2, "ring attn fwd")
+    close(lse, torch.logsumexp(S, -1), 2e-3, 1e-3, "ring attn lse")
+    if not big(dev):
+        monkeypatch.setenv("MC_ATTN_RING", "0")
+        o0, lse0 = ops.attn_fwd(q, k, v, Nq, Nk, heads, d, nb, kv_bdiv=share)
+        close(o, o0, 2e-3, 2e-3, "ring vs register-staged forward")
+        close(lse, lse0, 1e-4, 1e-4, "ring vs register-staged lse")
+
+
 def test_cross_attention_fwd_bwd(backend):
     dev = backend
     heads, d, B, F_, N, Nk = 2, 40, 2, 3, 50, 77
