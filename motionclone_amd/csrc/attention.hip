@@ -381,24 +381,33 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
     }
 }
 
-// ---- forward, long sequences: K / V through an LDS-DMA ring ------------------------------------------------------------
-// Same arithmetic as attn_fwd_kernel (S^T = K Q^T tile by tile, online softmax in the exp2 domain, P^T as the B operand of the
-// PV MFMAs straight from the accumulators); what differs is everything around the MFMAs:
+// ---- forward, long sequences at d = 40: K / V through an LDS-DMA ring, softmax offset inside the MFMA ---------------------
+// Same mathematics as attn_fwd_kernel (S^T = K Q^T tile by tile, P^T as the B operand of the PV MFMAs straight from the
+// accumulators, fp32 statistics); everything around the MFMAs is different, because the old loop was bound by what sat BETWEEN
+// them (VALU 58 % / MFMA 26 % of the resident cycles, 44 % of the wave time waiting: profiles/r03_pmc_sq_gemm_attention.md):
 //   * K and V tiles (64 keys) arrive by LDS-DMA (buffer_load ... lds) into a ring of three stages, two tiles ahead of their
 //     use: no staging registers, no VALU, no exposed load latency, ONE bare barrier per tile (the old loop had two, with the
 //     global load between them);
 //   * both images are row-major [64][32 DT bytes].  K fragments are 16-byte reads (the contraction index is permuted so a lane's
 //     8 k-slots are 8 adjacent head-dim elements; chunks of rows 8..15 of every 16 are swapped pairwise, which makes the reads
 //     conflict-free); V^T fragments come from the SAME row-major layout through the hardware transpose read
-//     (ds_read_b64_tr_b16; the 24 / 40-dword pitch is conflict-free for it) - the register transpose and its packed writes are gone;
-//   * head-dim padding is hardware zero fill: the chunk [d, 16 DT) of every row is fetched out of range.  At d = 40 the ones row
-//     that makes the PV MFMAs produce the softmax denominators is OR-ed into the one lane's V^T fragment that holds row d;
-//   * the 16-wide remainder of the head dim (d = 40: 8 live + 8 zero; d = 80: 16) runs as ONE v_mfma_f32_16x16x16_f16 issued
-//     FIRST on a zero accumulator, the 32-wide steps accumulate on top (4 independent MFMAs later): 24 instead of 32 MFMA
-//     cycles per 16 x 16 scores at d = 40;
-//   * the softmax's cross-row max is two VALU lane swaps (rows_max), not two ds_bpermute round trips;
+//     (ds_read_b64_tr_b16; the 24-dword pitch is conflict-free for it) - the register transpose and its packed writes are gone;
+//   * head-dim padding is hardware zero fill: the chunk [d, 16 DT) of every row is fetched out of range.  The ones row that
+//     makes the PV MFMAs produce the softmax denominators is OR-ed into the one lane's V^T fragment that holds row d;
+//   * THE SOFTMAX OFFSET RIDES IN A PADDING K-SLOT.  Q is pre-multiplied by scale * log2(e) when its fragments are loaded, one
+//     padding slot of the head dim holds 1.0 on the K side and -m[q] on the Q side, so the MFMA returns s * scale * log2(e) -
+//     m[q] and a score costs ONE v_exp_f32 and half a packed convert - no FMA, no running-max update.  m[q] is an offset, not
+//     the maximum: it only has to keep 2^(s - m) inside fp16, so it is re-based (output and denominators rescaled, as in any
+//     online softmax) only when a score of the tile exceeds it by more than 2^8 - the first tile always, a handful of times
+//     after.  The detection is a per-lane compare of the lane's own 16 scores (no cross-lane reduction on the common path);
+//     the re-base takes the row maximum with two VALU lane swaps (rows_max), not ds_bpermute round trips.  Because the SAME
+//     fp16 offset multiplies every key of a row, its rounding cancels in the normalisation;
 //   * per query tile the order is softmax(t) -> PV(t), so the VALU of tile t + 1 issues under the MFMAs of tile t.
-template <int DT, int QT, bool LEG>
+// The 16-wide remainder of the head dim runs as a zero-extended 32-wide step: v_mfma_f32_16x16x16_f16 occupies the pipe for the
+// same 16 cycles (tools/issue_rate.py), and mixed with 16x16x32 on one accumulator it returned wrong sums on gfx950 (again in
+// this kernel: 5 of 18 GPU tests failed with it, the simulator passed).
+constexpr float kRebase = 8.0f;   // re-base a row's offset when 2^(score - offset) would pass 2^8
+template <int DT, int QT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t* o, int ldo, float* lse) {
     constexpr int CPR = 2 * DT;          // 16-byte chunks per image row
     constexpr int PB = 32 * DT;          // row pitch, bytes
@@ -407,7 +416,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
     constexpr int NSTG = 3;
     constexpr int IPW = 2 * CPR / 4;     // LDS-DMA instructions per wave and tile (K + V = 2 CPR KiB over 4 waves)
     constexpr int NMAIN = DT / 2;        // 32-wide steps of the head dim
-    constexpr bool ODD = DT & 1;         // a 16-wide remainder
+    static_assert(DT & 1, "needs the 16-wide remainder step: its padding k-slots carry the softmax offset");
     static_assert((2 * CPR) % 4 == 0, "stage must split evenly over the four waves");
     MC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63;
@@ -424,7 +433,6 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
     const int q0 = xb * (64 * QT) + wave * (16 * QT);
     const int vpr = P.d / 8;
     const float sl2 = P.scale * 1.4426950408889634f;
-    const bool ones_row = P.d < DT * 16;
     const int nk = (P.Nk + KV_TILE - 1) / KV_TILE;
 
     // ---- LDS-DMA slots of this lane: instruction n = wave + 4 i fills chunks [64 (n % CPR), +64) of K (n < CPR) or V
@@ -451,16 +459,25 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
             else glds16(kbuf, dma_off[i] + ko, stg + n * 1024);
         }
     };
-    // ---- Q fragments (B operand): 32-wide step s holds head-dim [32 s + 8 g, +8), the remainder [32 NMAIN + 4 g, +4)
+
+    // ---- Q fragments (B operand), pre-multiplied by scale * log2(e): 32-wide step s holds head-dim [32 s + 8 g, +8), the
+    // remainder step [32 NMAIN + 4 g, +4) followed by 4 padding slots; the offset slot is k-slot 4 of lane group 0.
     half8_t qm[QT][NMAIN > 0 ? NMAIN : 1];
-    half4_t qr[QT];
+    half4_t qr[QT], qx[QT];
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qi = q0 + 16 * t + c15;
         const half_t* qp = P.q + (qbase + qi) * P.ldq + col0;
 #pragma unroll
-        for (int s2 = 0; s2 < NMAIN; ++s2) qm[t][s2] = qi < P.Nq ? ld8(qp + 32 * s2 + 8 * g) : zero8();
-        if (ODD) qr[t] = (qi < P.Nq && 32 * NMAIN + 4 * g < P.d) ? ld4(qp + 32 * NMAIN + 4 * g) : zero4();
+        for (int s2 = 0; s2 < NMAIN; ++s2) {
+            qm[t][s2] = qi < P.Nq ? ld8(qp + 32 * s2 + 8 * g) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qm[t][s2][e] = (half_t)((float)qm[t][s2][e] * sl2);
+        }
+        qr[t] = (qi < P.Nq && 32 * NMAIN + 4 * g < P.d) ? ld4(qp + 32 * NMAIN + 4 * g) : zero4();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) qr[t][e] = (half_t)((float)qr[t][e] * sl2);
+        qx[t] = zero4();
     }
     issue(0);
     if (nk > 1) issue(1);
@@ -471,15 +488,14 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
     for (int t = 0; t < QT; ++t) {
 #pragma unroll
         for (int s2 = 0; s2 < NMAIN; ++s2) asm volatile("" ::"v"(qm[t][s2]));
-        if (ODD) asm volatile("" ::"v"(qr[t]));
+        asm volatile("" ::"v"(qr[t]));
     }
 #endif
     f32x4 oacc[QT][DT];
-    float m[QT], l[QT];
+    float mfix[QT];   // the row's offset, exactly the fp16 value that sits in the Q fragment
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
-        m[t] = -INFINITY;
-        l[t] = 0.f;
+        mfix[t] = 0.f;
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) oacc[t][dt] = fzero4();
     }
@@ -489,7 +505,10 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
     const int k_rem = c15 * PB + ((4 * NMAIN + ((g >> 1) ^ swz)) << 4) + 8 * (g & 1);
     const int v_tr = IMG + (4 * g + (c15 >> 2)) * PB + 8 * (c15 & 3);
     // the lane of the last V^T fragment that holds row d (= softmax denominators): fp16 1.0 in all its k-slots
-    const uint32_t ones_bits = (ones_row && c15 == (P.d & 15)) ? 0x3C003C00u : 0u;
+    const uint32_t ones_bits = c15 == (P.d & 15) ? 0x3C003C00u : 0u;
+    // K side of the offset slot: 1.0 for every key
+    half4_t k_one = zero4();
+    if (g == 0) k_one[0] = (half_t)1.0f;
 
     for (int kt = 0; kt < nk; ++kt) {
         // my part of tile kt has landed (the younger tile may still be in flight); behind the barrier everyone's has, and
@@ -505,23 +524,16 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const char* kj = stg + j * 16 * PB;
-            if (ODD && LEG) {
-                const half4_t kr = ld4(reinterpret_cast<const half_t*>(kj + k_rem));
-#pragma unroll
-                for (int t = 0; t < QT; ++t) st[t][j] = mfma16(kr, qr[t], fzero4());
-            }
+            const half4_t kr = ld4(reinterpret_cast<const half_t*>(kj + k_rem));
 #pragma unroll
             for (int s2 = 0; s2 < NMAIN; ++s2) {
                 const half8_t kf = ld8(reinterpret_cast<const half_t*>(kj + k_main + 64 * s2));
 #pragma unroll
-                for (int t = 0; t < QT; ++t)
-                    st[t][j] = mfma16k32(kf, qm[t][s2], ((!ODD || !LEG) && s2 == 0) ? fzero4() : st[t][j]);
+                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, qm[t][s2], s2 == 0 ? fzero4() : st[t][j]);
             }
-            if (ODD && !LEG) {   // A/B form: the remainder as a zero-extended 32-wide step behind the others
-                const half8_t kr = cat4(ld4(reinterpret_cast<const half_t*>(kj + k_rem)), zero4());
+            const half8_t kf = cat4(kr, k_one);
 #pragma unroll
-                for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kr, cat4(qr[t], zero4()), NMAIN == 0 ? fzero4() : st[t][j]);
-            }
+            for (int t = 0; t < QT; ++t) st[t][j] = mfma16k32(kf, cat4(qr[t], qx[t]), NMAIN == 0 ? fzero4() : st[t][j]);
         }
         // V^T fragments of the whole tile: [dt][jp] = keys {32 jp + 4 g + e, 32 jp + 16 + 4 g + e} x head-dim 16 dt + c15
         // (issued now, awaited in front of the first PV MFMA: the first query tile's softmax covers their latency)
@@ -542,6 +554,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
                     for (int i = 0; i < 4; ++i)
                         if (16 * j + i >= live) st[t][j][i] = -INFINITY;
             }
+            // st = s * scale * log2(e) - mfix.  Largest of this lane's 16 scores: only to notice a row outgrowing its offset
             float mx = max3(st[t][0][0], st[t][0][1], st[t][0][2]);
             mx = max3(mx, st[t][0][3], st[t][1][0]);
             mx = max3(mx, st[t][1][1], st[t][1][2]);
@@ -550,44 +563,45 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
             mx = max3(mx, st[t][2][3], st[t][3][0]);
             mx = max3(mx, st[t][3][1], st[t][3][2]);
             mx = fmaxf(mx, st[t][3][3]);
-            mx = rows_max(mx);
-            const float mnew = fmaxf(m[t], mx * sl2);
-            float rs = 0.f;
+            if (kt == 0 || wave_any(mx > kRebase)) {
+                // re-base: new offset = the row's current maximum (first tile) or the larger of the two, rounded to the fp16 it
+                // is stored as; this tile's scores move by the difference on the VALU, the accumulators (output rows and, in the
+                // ones row, the denominators) by 2^-difference
+                mx = rows_max(mx);
+                float mnew = (float)(half_t)(mfix[t] + mx);
+                if (kt != 0) mnew = fmaxf(mnew, mfix[t]);
+                const float delta = mnew - mfix[t];
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) st[t][j][i] -= delta;
+                const float alpha = fast_exp2(-delta);
+#pragma unroll
+                for (int dt = 0; dt < DT; ++dt) scale_in_place(oacc[t][dt], alpha);
+                mfix[t] = mnew;
+                if (g == 0) qx[t][0] = (half_t)(-mnew);
+            }
             half8_t pf[2];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int i = 0; i < 4; i += 2) {
-                    const float e0 = fast_exp2(fmaf(st[t][j][i], sl2, -mnew));
-                    const float e1 = fast_exp2(fmaf(st[t][j][i + 1], sl2, -mnew));
-                    if (!ones_row) rs += e0 + e1;
-                    const half2_t h2 = pk_rtz(e0, e1);
+                    const half2_t h2 = pk_rtz(fast_exp2(st[t][j][i]), fast_exp2(st[t][j][i + 1]));
                     pf[j >> 1][4 * (j & 1) + i] = h2[0];
                     pf[j >> 1][4 * (j & 1) + i + 1] = h2[1];
                 }
-            if (!ones_row) rs = rows_sum(rs);
-            // the output rescale only when a running max moved (rare after the first tiles), in place
-            const float alpha = fast_exp2(m[t] - mnew);   // m = mnew = -inf cannot happen: a tile always holds a live key
-            l[t] = l[t] * alpha + rs;
-            if (!wave_all(mnew == m[t])) {
-#pragma unroll
-                for (int dt = 0; dt < DT; ++dt) scale_in_place(oacc[t][dt], alpha);
-            }
-            m[t] = mnew;
             if (t == 0) {
                 lds_tr_wait();
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) lds_tr_use(vf[dt][jp]);
-                if (ones_row) {
 #pragma unroll
-                    for (int jp = 0; jp < 2; ++jp) {
-                        u32x4 w = __builtin_bit_cast(u32x4, vf[DT - 1][jp]);
+                for (int jp = 0; jp < 2; ++jp) {
+                    u32x4 w = __builtin_bit_cast(u32x4, vf[DT - 1][jp]);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) w[i] |= ones_bits;
-                        vf[DT - 1][jp] = __builtin_bit_cast(half8_t, w);
-                    }
+                    for (int i = 0; i < 4; ++i) w[i] |= ones_bits;
+                    vf[DT - 1][jp] = __builtin_bit_cast(half8_t, w);
                 }
             }
 #pragma unroll
@@ -600,7 +614,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         const int qi = q0 + 16 * t + c15;
-        const float lt = ones_row ? shfl(oacc[t][DT - 1][0], 16 * ((P.d & 15) >> 2) + c15) : l[t];
+        // O^T row d (the denominators) sits in accumulator tile DT-1, element 0 of lane group (d % 16) / 4
+        const float lt = shfl(oacc[t][DT - 1][0], 16 * ((P.d & 15) >> 2) + c15);
         if (qi >= P.Nq) continue;
         const float inv = 1.0f / lt;
 #pragma unroll
@@ -613,7 +628,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
                 st4(o + (qbase + qi) * ldo + col0 + c, ov);
             }
         }
-        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = (m[t] + log2f(lt)) * 0.6931471805599453f;
+        if (g == 0 && lse) lse[((size_t)b * P.heads + h) * P.Nq + qi] = (mfix[t] + log2f(lt)) * 0.6931471805599453f;
     }
 }
 
@@ -905,12 +920,12 @@ static void a_launch_fwd_cfg(const AParams& P, half_t* o, int ldo, float* lse, h
 // (profiles/r01_attention_config_sweep.txt): two query tiles per wave win at every level (half the LDS traffic per
 // query); the register prefetch never pays - the loop is VALU-bound on the softmax and occupancy matters more.
 // MC_ATTN_QT / MC_ATTN_PF override the choice for experiments.
-template <int DT, int QT, bool LEG>
+template <int DT, int QT>
 static void a_launch_fwd_ring(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
     size_t smem = (size_t)3 * 2 * KV_TILE * 32 * DT;
-    allow_big_smem(attn_fwd_ring_kernel<DT, QT, LEG>, smem);
+    allow_big_smem(attn_fwd_ring_kernel<DT, QT>, smem);
     dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
-    MC_LAUNCH((attn_fwd_ring_kernel<DT, QT, LEG>), grid, dim3(256), smem, s, P, o, ldo, lse);
+    MC_LAUNCH((attn_fwd_ring_kernel<DT, QT>), grid, dim3(256), smem, s, P, o, ldo, lse);
 }
 
 // MC_ATTN_RING: 0 = never the LDS-DMA ring kernel, 2 = at every size it supports (tests), default = long sequences
@@ -929,12 +944,9 @@ static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipSt
     static const int pf_env = getenv("MC_ATTN_PF") ? atoi(getenv("MC_ATTN_PF")) : -1;
     if constexpr (DT == 3) {
         const int ring = attn_ring_env();
-        if (!P.causal && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512))) {
-            // remainder step: the 16-wide legacy MFMA passes every test and measures 0.6-1.2 % faster (the loop is VALU-bound),
-            // but mixed MFMA shapes on one accumulator have returned wrong sums on gfx950 before - not worth it
-            static const int leg_env = getenv("MC_ATTN_LEG") ? atoi(getenv("MC_ATTN_LEG")) : 0;
-            if (leg_env) a_launch_fwd_ring<DT, 4, true>(P, o, ldo, lse, s);
-            else a_launch_fwd_ring<DT, 4, false>(P, o, ldo, lse, s);
+        // (d = 40 exactly: the kernel needs the padding row of V^T and the padding k-slots of the remainder step)
+        if (!P.causal && P.d == 40 && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512))) {
+            a_launch_fwd_ring<DT, 4>(P, o, ldo, lse, s);
             return;
         }
     }

@@ -198,9 +198,11 @@ __device__ inline bool wave_all(bool p) {
     for (int m = 32; m >= 1; m >>= 1) v &= hipemu::shfl_xor(v, m);
     return v != 0;
 }
+__device__ inline bool wave_any(bool p) { return !wave_all(!p); }
 __device__ inline float fast_exp2(float x) { return exp2f(x); }
 #else
 __device__ __forceinline__ bool wave_all(bool p) { return __all(p); }
+__device__ __forceinline__ bool wave_any(bool p) { return __any(p); }
 __device__ __forceinline__ float fast_exp2(float x) { return __builtin_amdgcn_exp2f(x); }
 #endif
 
