@@ -406,6 +406,9 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
 // The 16-wide remainder of the head dim runs as a zero-extended 32-wide step: v_mfma_f32_16x16x16_f16 occupies the pipe for the
 // same 16 cycles (tools/issue_rate.py), and mixed with 16x16x32 on one accumulator it returned wrong sums on gfx950 (again in
 // this kernel: 5 of 18 GPU tests failed with it, the simulator passed).
+#ifndef MC_ATTN_DKDV_KT
+#define MC_ATTN_DKDV_KT 4   // key tiles (16 rows) per wave in attn_bwd_dkdv_ring_kernel
+#endif
 constexpr float kRebase = 8.0f;   // re-base a row's offset when 2^(score - offset) would pass 2^8
 template <int DT, int QT>
 __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t* o, int ldo, float* lse) {
@@ -901,6 +904,417 @@ __global__ __launch_bounds__(256, (KT == 1 && DT <= 4) ? 4 : ((KT == 1 && DT == 
     }
 }
 
+// ---- backward at d = 40, long sequences: the same LDS-DMA ring around the backward MFMAs --------------------------------------
+// Shared by the two kernels below: a 64-row tile of a [rows, ld] fp16 matrix (this head's d columns) as a row-major LDS image
+// [64][32 DT bytes]; chunks at / beyond d are fetched out of range (hardware zeros); the 16-byte chunks of rows 8..15 of every
+// 16 are swapped pairwise (conflict-free 16-byte row reads).  Both operand orientations are read from this one image: rows as
+// MFMA fragments directly, columns through the transpose read - the transposed LDS copies of the old kernels are gone.
+template <int DT>
+struct RingImage {
+    static constexpr int CPR = 2 * DT, PB = 32 * DT, BYTES = KV_TILE * PB;
+    // byte offset (from the buffer base) of what LDS-DMA instruction `inst` (0 .. CPR-1) of this image fetches for `lane`
+    static __device__ __forceinline__ uint32_t dma_offset(int inst, int lane, int ld, int col0, int vpr) {
+        const int pch = inst * 64 + lane;
+        const int row = pch / CPR, cp = pch % CPR;
+        const int c = cp ^ ((row >> 3) & 1);
+        return c < vpr ? (uint32_t)(row * ld + col0 + 8 * c) * 2 : kOOB;
+    }
+    // row fragments of row 16 j + c15: 32-wide step s (head-dim [32 s + 8 g, +8)) and the 16-wide remainder ([32 NMAIN + 4 g, +4))
+    static __device__ __forceinline__ int row_main(int c15, int g) { return c15 * PB + ((g ^ ((c15 >> 3) & 1)) << 4); }
+    static __device__ __forceinline__ int row_rem(int c15, int g) {
+        return c15 * PB + ((4 * (DT / 2) + ((g >> 1) ^ ((c15 >> 3) & 1))) << 4) + 8 * (g & 1);
+    }
+    // transpose-read base of a lane: rows {r0 + 4 g + e}, column 16 dt + c15 -> + (r0 * PB + 32 dt) as the immediate
+    static __device__ __forceinline__ int col_base(int c15, int g) {
+        return (4 * g + (c15 >> 2)) * PB + (((((c15 & 3) >> 1) ^ ((g >> 1) & 1))) << 4) + 8 * (c15 & 1);
+    }
+};
+
+// dQ (and D = rowsum(dO * O)).  S^T and dP^T tiles as in attn_bwd_dq_kernel, with BOTH per-row constants inside the MFMAs: Q is
+// pre-multiplied by scale * log2(e) and two padding k-slots carry -lse[q] * log2(e) (hi + lo fp16 parts: this one is the real
+// normaliser, its rounding does not cancel) against 1.0 on the K side, so P = exp2(accumulator); two more carry -D[q] against
+// 1.0 on the V side, so the second accumulator is dP - D.  Per score: one v_exp_f32, one multiply, half a packed convert.
+// Keys past Nk need no mask: their K rows are hardware zeros, so whatever dS they produce multiplies a zero row in dQ += dS K.
+template <int DT, int QT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dq_ring_kernel(AParams P, const half_t* o, int ldo, const half_t* dO,
+                                                                   int lddo, const float* lse, float* Dbuf, half_t* dq, int lddq) {
+    using Img = RingImage<DT>;
+    constexpr int PB = Img::PB, IMG = Img::BYTES, STAGE = 2 * IMG, NSTG = 3, CPR = Img::CPR;
+    constexpr int IPW = 2 * CPR / 4;
+    constexpr int NMAIN = DT / 2;
+    static_assert(DT & 1, "needs the padding k-slots of the 16-wide remainder step");
+    MC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63;
+#ifdef MC_EMU
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
+    const int g = lane >> 4, c15 = lane & 15;
+    int xb, h, b;
+    if (!attn_block(P, (P.Nq + 64 * QT - 1) / (64 * QT), xb, h, b)) return;
+    const int col0 = h * P.d;
+    const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)(b / P.kv_bdiv) * P.Nk;
+    const int q0 = xb * (64 * QT) + wave * (16 * QT);
+    const int vpr = P.d / 8;
+    const float sl2 = P.scale * 1.4426950408889634f;
+    const int nk = (P.Nk + KV_TILE - 1) / KV_TILE;
+
+    const GBuf kbuf = make_gbuf(P.k + kbase * P.ldk, (uint32_t)P.Nk * P.ldk * 2);
+    const GBuf vbuf = make_gbuf(P.v + kbase * P.ldv, (uint32_t)P.Nk * P.ldv * 2);
+    uint32_t dma_off[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int n = wave + 4 * i;
+        dma_off[i] = n >= CPR ? Img::dma_offset(n - CPR, lane, P.ldv, col0, vpr) : Img::dma_offset(n, lane, P.ldk, col0, vpr);
+    }
+    auto issue = [&](int tile) {
+        char* stg = smem + (tile % NSTG) * STAGE;
+        const uint32_t ko = (uint32_t)tile * KV_TILE * P.ldk * 2, vo = (uint32_t)tile * KV_TILE * P.ldv * 2;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int n = wave + 4 * i;
+            if (n >= CPR) glds16(vbuf, dma_off[i] + vo, stg + IMG + (n - CPR) * 1024);
+            else glds16(kbuf, dma_off[i] + ko, stg + n * 1024);
+        }
+    };
+
+    // Q' = Q * scale * log2(e) and dO as B-operand fragments; the remainder step's upper half holds the row constants
+    half8_t qm[QT][NMAIN > 0 ? NMAIN : 1], dom[QT][NMAIN > 0 ? NMAIN : 1];
+    half4_t qr[QT], qx[QT], dor[QT], dx[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + 16 * t + c15;
+        const bool qok = qi < P.Nq;
+        const half_t* qp = P.q + (qbase + qi) * P.ldq + col0;
+        const half_t* dp = dO + (qbase + qi) * lddo + col0;
+        const half_t* op = o + (qbase + qi) * ldo + col0;
+        float dsum = 0.f;
+#pragma unroll
+        for (int s2 = 0; s2 < NMAIN; ++s2) {
+            const half8_t qv = qok ? ld8(qp + 32 * s2 + 8 * g) : zero8();
+            dom[t][s2] = qok ? ld8(dp + 32 * s2 + 8 * g) : zero8();
+            const half8_t ov = qok ? ld8(op + 32 * s2 + 8 * g) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                qm[t][s2][e] = (half_t)((float)qv[e] * sl2);
+                dsum += (float)dom[t][s2][e] * (float)ov[e];
+            }
+        }
+        const bool rok = qok && 32 * NMAIN + 4 * g < P.d;
+        const half4_t qv = rok ? ld4(qp + 32 * NMAIN + 4 * g) : zero4();
+        dor[t] = rok ? ld4(dp + 32 * NMAIN + 4 * g) : zero4();
+        const half4_t ov = rok ? ld4(op + 32 * NMAIN + 4 * g) : zero4();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            qr[t][e] = (half_t)((float)qv[e] * sl2);
+            dsum += (float)dor[t][e] * (float)ov[e];
+        }
+        const float Dq = rows_sum(dsum);
+        const size_t sidx = ((size_t)b * P.heads + h) * P.Nq + (qok ? qi : 0);
+        const float lq2 = qok ? lse[sidx] * 1.4426950408889634f : 0.f;
+        if (qok && g == 0 && Dbuf) Dbuf[sidx] = Dq;
+        qx[t] = zero4();
+        dx[t] = zero4();
+        if (g == 0) {
+            const half_t lh = (half_t)lq2, dh = (half_t)Dq;
+            qx[t][0] = -lh;
+            qx[t][1] = (half_t)((float)lh - lq2);
+            dx[t][0] = -dh;
+            dx[t][1] = (half_t)((float)dh - Dq);
+        }
+    }
+    issue(0);
+    if (nk > 1) issue(1);
+#ifndef MC_EMU
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {   // pins hipcc's wait for the loads above in front of the loop (see attn_fwd_ring_kernel)
+#pragma unroll
+        for (int s2 = 0; s2 < NMAIN; ++s2) {
+            asm volatile("" ::"v"(qm[t][s2]));
+            asm volatile("" ::"v"(dom[t][s2]));
+        }
+        asm volatile("" ::"v"(qr[t]), "v"(dor[t]), "v"(qx[t]), "v"(dx[t]));
+    }
+#endif
+    f32x4 acc[QT][DT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) acc[t][dt] = fzero4();
+    const int r_main = Img::row_main(c15, g), r_rem = Img::row_rem(c15, g), c_base = Img::col_base(c15, g);
+    half4_t one2 = zero4();   // 1.0 in the two constant slots, K / V side
+    if (g == 0) one2[0] = one2[1] = (half_t)1.0f;
+
+    for (int kt = 0; kt < nk; ++kt) {
+        if (kt + 1 < nk) wait_vmcnt_le<IPW>();
+        else wait_vmcnt_le<0>();
+        raw_barrier();
+        if (kt + 2 < nk) issue(kt + 2);
+        const char* stg = smem + (kt % NSTG) * STAGE;
+        static_for<2>([&](auto jp_) {
+            constexpr int jp = decltype(jp_)::value;
+            // K^T fragments of this half tile (keys 32 jp ..): issued now, awaited in front of the dQ MFMAs
+            half8_t k8[DT];
+            static_for<DT>([&](auto dt_) {
+                constexpr int dt = decltype(dt_)::value;
+                k8[dt] = cat4(lds_read_tr4_async<32 * jp * PB + 32 * dt>(stg + c_base),
+                              lds_read_tr4_async<(32 * jp + 16) * PB + 32 * dt>(stg + c_base));
+            });
+            half4_t dsf[QT][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const char* kj = stg + (2 * jp + jj) * 16 * PB;
+                f32x4 sT[QT], dpT[QT];
+#pragma unroll
+                for (int s2 = 0; s2 < NMAIN; ++s2) {
+                    const half8_t kf = ld8(reinterpret_cast<const half_t*>(kj + r_main + 64 * s2));
+                    const half8_t vf = ld8(reinterpret_cast<const half_t*>(kj + IMG + r_main + 64 * s2));
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        sT[t] = mfma16k32(kf, qm[t][s2], s2 == 0 ? fzero4() : sT[t]);
+                        dpT[t] = mfma16k32(vf, dom[t][s2], s2 == 0 ? fzero4() : dpT[t]);
+                    }
+                }
+                const half8_t kf = cat4(ld4(reinterpret_cast<const half_t*>(kj + r_rem)), one2);
+                const half8_t vf = cat4(ld4(reinterpret_cast<const half_t*>(kj + IMG + r_rem)), one2);
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    sT[t] = mfma16k32(kf, cat4(qr[t], qx[t]), NMAIN == 0 ? fzero4() : sT[t]);
+                    dpT[t] = mfma16k32(vf, cat4(dor[t], dx[t]), NMAIN == 0 ? fzero4() : dpT[t]);
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    const half2_t a = pk_rtz(fast_exp2(sT[t][0]) * dpT[t][0], fast_exp2(sT[t][1]) * dpT[t][1]);
+                    const half2_t c = pk_rtz(fast_exp2(sT[t][2]) * dpT[t][2], fast_exp2(sT[t][3]) * dpT[t][3]);
+                    dsf[t][jj][0] = a[0]; dsf[t][jj][1] = a[1]; dsf[t][jj][2] = c[0]; dsf[t][jj][3] = c[1];
+                }
+            }
+            lds_tr_wait();
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) lds_tr_use(k8[dt]);
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int t = 0; t < QT; ++t) acc[t][dt] = mfma16k32(k8[dt], cat4(dsf[t][0], dsf[t][1]), acc[t][dt]);
+        });
+    }
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int qi = q0 + 16 * t + c15;
+        if (qi >= P.Nq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = 16 * dt + 4 * g;
+            if (c < P.d) {
+                half4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = to_half(acc[t][dt][i] * P.scale);
+                st4(dq + (qbase + qi) * lddq + col0 + c, ov);
+            }
+        }
+    }
+}
+
+// dK, dV (self-attention).  Q and dO tiles (64 query rows) stream through the ring together with the rows' lse and D (one more
+// 16-byte-per-lane LDS-DMA instruction per tile: 64 + 64 floats); K (pre-multiplied by scale * log2(e)) and V stay in registers as
+// B-operand fragments.  The row constants vary along the ACCUMULATOR ROWS here (A side = the LDS images), so they stay on the
+// VALU: per score one subtract, one v_exp_f32, a subtract and a multiply, one packed convert.  Query rows past Nq are hardware
+// zeros with lse = D = 0: P = 1 and dO = 0 there, so they add nothing to dV or dK.
+template <int DT, int KT>
+__global__ __launch_bounds__(256, 2) void attn_bwd_dkdv_ring_kernel(AParams P, const half_t* dO, int lddo, const float* lse,
+                                                                     const float* Dbuf, half_t* dk, int lddk, half_t* dv, int lddv) {
+    using Img = RingImage<DT>;
+    constexpr int PB = Img::PB, IMG = Img::BYTES, STAGE = 2 * IMG + 2048, NSTG = 3, CPR = Img::CPR;
+    constexpr int IPW = 2 * CPR / 4;     // + 1 on waves 0 and 1: the lse / D chunks
+    constexpr int NMAIN = DT / 2;
+    static_assert(DT & 1, "written for the 16-wide remainder step");
+    MC_DYN_SMEM(smem);
+    const int lane = threadIdx.x & 63;
+#ifdef MC_EMU
+    const int wave = threadIdx.x >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#endif
+    const int g = lane >> 4, c15 = lane & 15;
+    int xb, h, b;
+    if (!attn_block(P, (P.Nk + 64 * KT - 1) / (64 * KT), xb, h, b)) return;
+    const int col0 = h * P.d;
+    const size_t qbase = (size_t)b * P.Nq, kbase = (size_t)b * P.Nk;
+    const int k0 = xb * (64 * KT) + wave * (16 * KT);
+    const int vpr = P.d / 8;
+    const float sl2 = P.scale * 1.4426950408889634f;
+    const int nq = (P.Nq + KV_TILE - 1) / KV_TILE;
+
+    const GBuf qbuf = make_gbuf(P.q + qbase * P.ldq, (uint32_t)P.Nq * P.ldq * 2);
+    const GBuf obuf = make_gbuf(dO + qbase * lddo, (uint32_t)P.Nq * lddo * 2);
+    const size_t stat0 = ((size_t)b * P.heads + h) * P.Nq;
+    const GBuf lbuf = make_gbuf(lse + stat0, (uint32_t)P.Nq * 4);
+    const GBuf dbuf = make_gbuf(Dbuf + stat0, (uint32_t)P.Nq * 4);
+    uint32_t dma_off[IPW];
+#pragma unroll
+    for (int i = 0; i < IPW; ++i) {
+        const int n = wave + 4 * i;
+        dma_off[i] = n >= CPR ? Img::dma_offset(n - CPR, lane, lddo, col0, vpr) : Img::dma_offset(n, lane, P.ldq, col0, vpr);
+    }
+    // lanes 0..15 of one instruction: the tile's 64 lse (wave 0) or D (wave 1) values; the other lanes write zeros behind them
+    const uint32_t stat_off = lane < 16 ? (uint32_t)lane * 16 : kOOB;
+    auto issue = [&](int tile) {
+        char* stg = smem + (tile % NSTG) * STAGE;
+        const uint32_t qo = (uint32_t)tile * KV_TILE * P.ldq * 2, oo = (uint32_t)tile * KV_TILE * lddo * 2;
+#pragma unroll
+        for (int i = 0; i < IPW; ++i) {
+            const int n = wave + 4 * i;
+            if (n >= CPR) glds16(obuf, dma_off[i] + oo, stg + IMG + (n - CPR) * 1024);
+            else glds16(qbuf, dma_off[i] + qo, stg + n * 1024);
+        }
+        const uint32_t so = stat_off + (uint32_t)tile * KV_TILE * 4;
+        if (wave == 0) glds16(lbuf, so, stg + 2 * IMG);
+        if (wave == 1) glds16(dbuf, so, stg + 2 * IMG + 1024);
+    };
+
+    // K' = K * scale * log2(e) and V as B-operand fragments (remainder step zero-extended)
+    // (remainder step: K in k-slots 0-3 and V in k-slots 4-7 of ONE fragment; the Q / dO side zeroes the half it does not want)
+    half8_t km[KT][NMAIN > 0 ? NMAIN : 1], vm[KT][NMAIN > 0 ? NMAIN : 1], kvr[KT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int kvi = k0 + 16 * t + c15;
+        const bool ok = kvi < P.Nk;
+        const half_t* kp = P.k + (kbase + kvi) * P.ldk + col0;
+        const half_t* vp = P.v + (kbase + kvi) * P.ldv + col0;
+#pragma unroll
+        for (int s2 = 0; s2 < NMAIN; ++s2) {
+            const half8_t kv = ok ? ld8(kp + 32 * s2 + 8 * g) : zero8();
+            vm[t][s2] = ok ? ld8(vp + 32 * s2 + 8 * g) : zero8();
+#pragma unroll
+            for (int e = 0; e < 8; ++e) km[t][s2][e] = (half_t)((float)kv[e] * sl2);
+        }
+        const bool rok = ok && 32 * NMAIN + 4 * g < P.d;
+        half4_t kv = rok ? ld4(kp + 32 * NMAIN + 4 * g) : zero4();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) kv[e] = (half_t)((float)kv[e] * sl2);
+        kvr[t] = cat4(kv, rok ? ld4(vp + 32 * NMAIN + 4 * g) : zero4());
+    }
+    issue(0);
+    if (nq > 1) issue(1);
+#ifndef MC_EMU
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+#pragma unroll
+        for (int s2 = 0; s2 < NMAIN; ++s2) {
+            asm volatile("" ::"v"(km[t][s2]));
+            asm volatile("" ::"v"(vm[t][s2]));
+        }
+        asm volatile("" ::"v"(kvr[t]));
+    }
+#endif
+    f32x4 ak[KT][DT], av[KT][DT];
+#pragma unroll
+    for (int t = 0; t < KT; ++t)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) ak[t][dt] = av[t][dt] = fzero4();
+    const int r_main = Img::row_main(c15, g), r_rem = Img::row_rem(c15, g), c_base = Img::col_base(c15, g);
+
+    for (int qt = 0; qt < nq; ++qt) {
+        // waves 0 and 1 have one more instruction per tile in flight (the lse / D chunks)
+        if (qt + 1 < nq) {
+            if (wave < 2) wait_vmcnt_le<IPW + 1>();
+            else wait_vmcnt_le<IPW>();
+        } else {
+            wait_vmcnt_le<0>();
+        }
+        raw_barrier();
+        if (qt + 2 < nq) issue(qt + 2);
+        const char* stg = smem + (qt % NSTG) * STAGE;
+        const float* stat = reinterpret_cast<const float*>(stg + 2 * IMG);   // [64] lse, +256 floats: [64] D
+        static_for<2>([&](auto jp_) {
+            constexpr int jp = decltype(jp_)::value;
+            // dO^T and Q^T fragments of this half tile (query rows 32 jp ..): read one head-dim tile ahead of their MFMAs
+            half8_t o8[2], q8[2];
+            auto fetch = [&](auto dt_, int slot) {
+                constexpr int dt = decltype(dt_)::value;
+                q8[slot] = cat4(lds_read_tr4_async<32 * jp * PB + 32 * dt>(stg + c_base),
+                                lds_read_tr4_async<(32 * jp + 16) * PB + 32 * dt>(stg + c_base));
+                o8[slot] = cat4(lds_read_tr4_async<IMG + 32 * jp * PB + 32 * dt>(stg + c_base),
+                                lds_read_tr4_async<IMG + (32 * jp + 16) * PB + 32 * dt>(stg + c_base));
+            };
+            half4_t pf[KT][2], dsf[KT][2];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const int j = 2 * jp + jj;
+                const char* qj = stg + j * 16 * PB;
+                f32x4 sc[KT], dp[KT];
+#pragma unroll
+                for (int s2 = 0; s2 < NMAIN; ++s2) {
+                    const half8_t qf = ld8(reinterpret_cast<const half_t*>(qj + r_main + 64 * s2));
+                    const half8_t of = ld8(reinterpret_cast<const half_t*>(qj + IMG + r_main + 64 * s2));
+#pragma unroll
+                    for (int t = 0; t < KT; ++t) {
+                        sc[t] = mfma16k32(qf, km[t][s2], s2 == 0 ? fzero4() : sc[t]);   // [q = 16 j + 4 g + i][kv = c15]
+                        dp[t] = mfma16k32(of, vm[t][s2], s2 == 0 ? fzero4() : dp[t]);
+                    }
+                }
+                const half8_t qf = cat4(ld4(reinterpret_cast<const half_t*>(qj + r_rem)), zero4());
+                const half8_t of = cat4(zero4(), ld4(reinterpret_cast<const half_t*>(qj + IMG + r_rem)));
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    sc[t] = mfma16k32(qf, kvr[t], NMAIN == 0 ? fzero4() : sc[t]);
+                    dp[t] = mfma16k32(of, kvr[t], NMAIN == 0 ? fzero4() : dp[t]);
+                }
+                f32x4 l4 = *reinterpret_cast<const f32x4*>(stat + 16 * j + 4 * g);
+                const f32x4 d4 = *reinterpret_cast<const f32x4*>(stat + 256 + 16 * j + 4 * g);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) l4[i] *= 1.4426950408889634f;
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    float pr[4], ds[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        pr[i] = fast_exp2(sc[t][i] - l4[i]);
+                        ds[i] = pr[i] * (dp[t][i] - d4[i]);
+                    }
+                    half2_t a = pk_rtz(pr[0], pr[1]), c = pk_rtz(pr[2], pr[3]);
+                    pf[t][jj][0] = a[0]; pf[t][jj][1] = a[1]; pf[t][jj][2] = c[0]; pf[t][jj][3] = c[1];
+                    a = pk_rtz(ds[0], ds[1]); c = pk_rtz(ds[2], ds[3]);
+                    dsf[t][jj][0] = a[0]; dsf[t][jj][1] = a[1]; dsf[t][jj][2] = c[0]; dsf[t][jj][3] = c[1];
+                }
+            }
+            fetch(std::integral_constant<int, 0>{}, 0);
+            static_for<DT>([&](auto dt_) {
+                constexpr int dt = decltype(dt_)::value;
+                lds_tr_wait();
+                lds_tr_use(o8[dt & 1]);
+                lds_tr_use(q8[dt & 1]);
+                if constexpr (dt + 1 < DT) fetch(std::integral_constant<int, dt + 1>{}, (dt + 1) & 1);
+#pragma unroll
+                for (int t = 0; t < KT; ++t) {
+                    av[t][dt] = mfma16k32(o8[dt & 1], cat4(pf[t][0], pf[t][1]), av[t][dt]);
+                    ak[t][dt] = mfma16k32(q8[dt & 1], cat4(dsf[t][0], dsf[t][1]), ak[t][dt]);
+                }
+            });
+        });
+    }
+#pragma unroll
+    for (int t = 0; t < KT; ++t) {
+        const int kvi = k0 + 16 * t + c15;
+        if (kvi >= P.Nk) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int c = 16 * dt + 4 * g;
+            if (c < P.d) {
+                half4_t ok, ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ok[i] = to_half(ak[t][dt][i] * P.scale);
+                    ov[i] = to_half(av[t][dt][i]);
+                }
+                st4(dk + (kbase + kvi) * lddk + col0 + c, ok);
+                st4(dv + (kbase + kvi) * lddv + col0 + c, ov);
+            }
+        }
+    }
+}
+
 static int a_check(const AParams& P) {
     if (P.Nq <= 0 || P.Nk <= 0 || P.heads <= 0 || P.d <= 0 || P.nbatch <= 0 || P.kv_bdiv <= 0) return 0;
     if (P.d % 8 || P.ldq % 8 || P.ldk % 8 || P.ldv % 8) return 0;
@@ -996,9 +1410,23 @@ static int bwd_tiles(int rows, int dt) {
     if (dt == 3 && rows >= 2048) return 4;
     return rows >= 512 ? 2 : 1;
 }
+static bool attn_bwd_ring_wanted(const AParams& P) {
+    const int ring = attn_ring_env();
+    // d = 40 exactly (padding k-slots); the D / lse chunks are fetched 16 bytes at a time
+    return P.d == 40 && P.Nq % 4 == 0 && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512));
+}
 template <int DT>
 static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse,
                         float* Dbuf, half_t* dq, int lddq, hipStream_t s) {
+    if constexpr (DT == 3) {
+        if (attn_bwd_ring_wanted(P) && lddo % 8 == 0 && ldo % 8 == 0) {
+            size_t smem = (size_t)3 * 2 * RingImage<DT>::BYTES;
+            allow_big_smem(attn_bwd_dq_ring_kernel<DT, 4>, smem);
+            dim3 grid = attn_grid(P, (P.Nq + 255) / 256);
+            MC_LAUNCH((attn_bwd_dq_ring_kernel<DT, 4>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
+            return;
+        }
+    }
     if constexpr (DT == 3) {   // four row tiles per wave
         if (bwd_tiles(P.Nq, DT) == 4) return a_launch_dq_cfg<DT, 4>(P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq, s);
     }
@@ -1010,6 +1438,16 @@ static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t
 template <int DT>
 static void a_launch_dkdv(const AParams& P, const half_t* dO, int lddo, const float* lse, const float* Dbuf,
                           half_t* dk, int lddk, half_t* dv, int lddv, hipStream_t s) {
+    if constexpr (DT == 3) {
+        if (attn_bwd_ring_wanted(P) && lddo % 8 == 0) {
+            constexpr int KT = MC_ATTN_DKDV_KT;
+            size_t smem = (size_t)3 * (2 * RingImage<DT>::BYTES + 2048);
+            allow_big_smem(attn_bwd_dkdv_ring_kernel<DT, KT>, smem);
+            dim3 grid = attn_grid(P, (P.Nk + 64 * KT - 1) / (64 * KT));
+            MC_LAUNCH((attn_bwd_dkdv_ring_kernel<DT, KT>), grid, dim3(256), smem, s, P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv);
+            return;
+        }
+    }
     if constexpr (DT == 3) {
         if (bwd_tiles(P.Nk, DT) == 4) return a_launch_dkdv_cfg<DT, 4>(P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv, s);
     }

@@ -469,6 +469,48 @@ def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share):
         close(lse, lse0, 1e-4, 1e-4, "ring vs register-staged lse")
 
 
+@pytest.mark.parametrize("Nq,Nk,share", [(148, 148, 1), (64, 64, 1), (300, 77, 3)])
+def test_attention_backward_ring_kernels(backend, monkeypatch, Nq, Nk, share):
+    """attention.hip attn_bwd_dq_ring_kernel / attn_bwd_dkdv_ring_kernel (d = 40 long sequences): lse and D carried in padding
+    k-slots of the dQ kernel's MFMAs, Q / dO / lse / D streamed by LDS-DMA in the dK / dV kernel.  Against autograd; ragged
+    tiles on both axes; dq only with shared keys (cross-attention).  Forced at these sizes on the emulator, default on the GPU."""
+    dev = backend
+    heads, d, nb = 2, 40, 2 * share
+    if big(dev):
+        Nq, Nk, heads = Nq * 8 + 4, (Nk * 8 + 4 if Nk != 77 else 77 * 8), 8
+        if share == 1:
+            Nk = Nq
+    C = heads * d
+    q = rnd((nb * Nq, C), dev, 31, 0.7)
+    kv = rnd((nb // share * Nk, 2 * C), dev, 32, 0.7)
+    k, v = kv[:, :C], kv[:, C:]
+    do = rnd((nb * Nq, C), dev, 33)
+    monkeypatch.setenv("MC_ATTN_RING", "2")
+    o, lse = ops.attn_fwd(q, k, v, Nq, Nk, heads, d, nb, kv_bdiv=share)
+    Q = _heads(q, nb, Nq, heads, d).requires_grad_()
+    K0 = _heads(k, nb // share, Nk, heads, d).requires_grad_()
+    V0 = _heads(v, nb // share, Nk, heads, d).requires_grad_()
+    K, V = K0.repeat_interleave(share, 0), V0.repeat_interleave(share, 0)
+    ref = ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ V
+    gq, gk, gv = torch.autograd.grad(ref, (Q, K0, V0), _heads(do, nb, Nq, heads, d))
+    if share == 1:
+        dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nb)
+        close(_heads(dk, nb, Nk, heads, d), gk, 1e-2, 2e-2, "ring attn dk")
+        close(_heads(dv, nb, Nk, heads, d), gv, 1e-2, 2e-2, "ring attn dv")
+    else:
+        dq, _, _ = ops.attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nb, kv_bdiv=share, need_dkv=False)
+    close(_heads(dq, nb, Nq, heads, d), gq, 1e-2, 2e-2, "ring attn dq")
+    if not big(dev):   # and against the register-staged kernels
+        monkeypatch.setenv("MC_ATTN_RING", "0")
+        if share == 1:
+            dq0, dk0, dv0 = ops.attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nb)
+            close(dk, dk0, 3e-3, 3e-3, "ring vs register-staged dk")
+            close(dv, dv0, 3e-3, 3e-3, "ring vs register-staged dv")
+        else:
+            dq0, _, _ = ops.attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nb, kv_bdiv=share, need_dkv=False)
+        close(dq, dq0, 3e-3, 3e-3, "ring vs register-staged dq")
+
+
 def test_cross_attention_fwd_bwd(backend):
     dev = backend
     heads, d, B, F_, N, Nk = 2, 40, 2, 3, 50, 77
