@@ -407,11 +407,14 @@ __global__ __launch_bounds__(256, (QT == 1 && DT <= 4) ? 4 : 2) void attn_fwd_ke
 // same 16 cycles (tools/issue_rate.py), and mixed with 16x16x32 on one accumulator it returned wrong sums on gfx950 (again in
 // this kernel: 5 of 18 GPU tests failed with it, the simulator passed).
 #ifndef MC_ATTN_DKDV_KT
-#define MC_ATTN_DKDV_KT 4   // key tiles (16 rows) per wave in attn_bwd_dkdv_ring_kernel
+#define MC_ATTN_DKDV_KT 4   // key tiles (16 rows) per wave in attn_bwd_dkdv_ring_kernel at d = 40
 #endif
 constexpr float kRebase = 8.0f;   // re-base a row's offset when 2^(score - offset) would pass 2^8
-template <int DT, int QT>
+// PADROW: the head dim leaves a padding row in V^T (d = 40) that becomes the ones row; otherwise (d = 80) the denominators take
+// one more output tile whose V^T fragment is a constant (row 0 = ones): two more MFMAs per query tile instead of 16 adds.
+template <int DT, int QT, bool PADROW>
 __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t* o, int ldo, float* lse) {
+    constexpr int DTO = DT + (PADROW ? 0 : 1);   // output tiles incl. the denominators' row
     constexpr int CPR = 2 * DT;          // 16-byte chunks per image row
     constexpr int PB = 32 * DT;          // row pitch, bytes
     constexpr int IMG = KV_TILE * PB;    // one matrix of one stage
@@ -494,13 +497,13 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
         asm volatile("" ::"v"(qr[t]));
     }
 #endif
-    f32x4 oacc[QT][DT];
+    f32x4 oacc[QT][DTO];
     float mfix[QT];   // the row's offset, exactly the fp16 value that sits in the Q fragment
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         mfix[t] = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt) oacc[t][dt] = fzero4();
+        for (int dt = 0; dt < DTO; ++dt) oacc[t][dt] = fzero4();
     }
     // per-lane read bases inside a stage (bytes)
     const int swz = (c15 >> 3) & 1;
@@ -508,7 +511,9 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
     const int k_rem = c15 * PB + ((4 * NMAIN + ((g >> 1) ^ swz)) << 4) + 8 * (g & 1);
     const int v_tr = IMG + (4 * g + (c15 >> 2)) * PB + 8 * (c15 & 3);
     // the lane of the last V^T fragment that holds row d (= softmax denominators): fp16 1.0 in all its k-slots
-    const uint32_t ones_bits = c15 == (P.d & 15) ? 0x3C003C00u : 0u;
+    const uint32_t ones_bits = c15 == (PADROW ? (P.d & 15) : 0) ? 0x3C003C00u : 0u;
+    u32x4 ones_w = {ones_bits, ones_bits, ones_bits, ones_bits};
+    const half8_t ones8 = __builtin_bit_cast(half8_t, ones_w);   // !PADROW: the constant V^T fragment of the extra tile
     // K side of the offset slot: 1.0 for every key
     half4_t k_one = zero4();
     if (g == 0) k_one[0] = (half_t)1.0f;
@@ -580,7 +585,7 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
                     for (int i = 0; i < 4; ++i) st[t][j][i] -= delta;
                 const float alpha = fast_exp2(-delta);
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt) scale_in_place(oacc[t][dt], alpha);
+                for (int dt = 0; dt < DTO; ++dt) scale_in_place(oacc[t][dt], alpha);
                 mfix[t] = mnew;
                 if (g == 0) qx[t][0] = (half_t)(-mnew);
             }
@@ -599,18 +604,24 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
                 for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                     for (int jp = 0; jp < 2; ++jp) lds_tr_use(vf[dt][jp]);
+                if (PADROW) {
 #pragma unroll
-                for (int jp = 0; jp < 2; ++jp) {
-                    u32x4 w = __builtin_bit_cast(u32x4, vf[DT - 1][jp]);
+                    for (int jp = 0; jp < 2; ++jp) {
+                        u32x4 w = __builtin_bit_cast(u32x4, vf[DT - 1][jp]);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] |= ones_bits;
-                    vf[DT - 1][jp] = __builtin_bit_cast(half8_t, w);
+                        for (int i = 0; i < 4; ++i) w[i] |= ones_bits;
+                        vf[DT - 1][jp] = __builtin_bit_cast(half8_t, w);
+                    }
                 }
             }
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt)
 #pragma unroll
                 for (int jp = 0; jp < 2; ++jp) oacc[t][dt] = mfma16k32(vf[dt][jp], pf[jp], oacc[t][dt]);
+            if (!PADROW) {
+#pragma unroll
+                for (int jp = 0; jp < 2; ++jp) oacc[t][DTO - 1] = mfma16k32(ones8, pf[jp], oacc[t][DTO - 1]);
+            }
         }
     }
 
@@ -618,7 +629,8 @@ __global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t
     for (int t = 0; t < QT; ++t) {
         const int qi = q0 + 16 * t + c15;
         // O^T row d (the denominators) sits in accumulator tile DT-1, element 0 of lane group (d % 16) / 4
-        const float lt = shfl(oacc[t][DT - 1][0], 16 * ((P.d & 15) >> 2) + c15);
+        // (!PADROW: row 0 of the extra tile)
+        const float lt = shfl(oacc[t][DTO - 1][0], (PADROW ? 16 * ((P.d & 15) >> 2) : 0) + c15);
         if (qi >= P.Nq) continue;
         const float inv = 1.0f / lt;
 #pragma unroll
@@ -1334,12 +1346,12 @@ static void a_launch_fwd_cfg(const AParams& P, half_t* o, int ldo, float* lse, h
 // (profiles/r01_attention_config_sweep.txt): two query tiles per wave win at every level (half the LDS traffic per
 // query); the register prefetch never pays - the loop is VALU-bound on the softmax and occupancy matters more.
 // MC_ATTN_QT / MC_ATTN_PF override the choice for experiments.
-template <int DT, int QT>
+template <int DT, int QT, bool PADROW>
 static void a_launch_fwd_ring(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
     size_t smem = (size_t)3 * 2 * KV_TILE * 32 * DT;
-    allow_big_smem(attn_fwd_ring_kernel<DT, QT>, smem);
+    allow_big_smem(attn_fwd_ring_kernel<DT, QT, PADROW>, smem);
     dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
-    MC_LAUNCH((attn_fwd_ring_kernel<DT, QT>), grid, dim3(256), smem, s, P, o, ldo, lse);
+    MC_LAUNCH((attn_fwd_ring_kernel<DT, QT, PADROW>), grid, dim3(256), smem, s, P, o, ldo, lse);
 }
 
 // MC_ATTN_RING: 0 = never the LDS-DMA ring kernel, 2 = at every size it supports (tests), default = long sequences
@@ -1356,11 +1368,13 @@ template <int DT>
 static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
     static const int qt_env = getenv("MC_ATTN_QT") ? atoi(getenv("MC_ATTN_QT")) : 0;
     static const int pf_env = getenv("MC_ATTN_PF") ? atoi(getenv("MC_ATTN_PF")) : -1;
-    if constexpr (DT == 3) {
+    if constexpr (DT == 3 || DT == 5) {
         const int ring = attn_ring_env();
-        // (d = 40 exactly: the kernel needs the padding row of V^T and the padding k-slots of the remainder step)
-        if (!P.causal && P.d == 40 && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512))) {
-            a_launch_fwd_ring<DT, 4>(P, o, ldo, lse, s);
+        // d = 40 / 80 exactly: the ring kernels need the padding k-slots of the 16-wide remainder step (and say which row of
+        // V^T carries the denominators)
+        if (!P.causal && P.d == (DT == 3 ? 40 : 80) && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512))) {
+            if constexpr (DT == 3) a_launch_fwd_ring<3, 4, true>(P, o, ldo, lse, s);
+            else a_launch_fwd_ring<5, 2, false>(P, o, ldo, lse, s);
             return;
         }
     }
@@ -1412,18 +1426,19 @@ static int bwd_tiles(int rows, int dt) {
 }
 static bool attn_bwd_ring_wanted(const AParams& P) {
     const int ring = attn_ring_env();
-    // d = 40 exactly (padding k-slots); the D / lse chunks are fetched 16 bytes at a time
-    return P.d == 40 && P.Nq % 4 == 0 && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512));
+    // d = 40 / 80 exactly (padding k-slots); the D / lse chunks are fetched 16 bytes at a time
+    return (P.d == 40 || P.d == 80) && P.Nq % 4 == 0 && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512));
 }
 template <int DT>
 static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse,
                         float* Dbuf, half_t* dq, int lddq, hipStream_t s) {
-    if constexpr (DT == 3) {
+    if constexpr (DT == 3 || DT == 5) {
         if (attn_bwd_ring_wanted(P) && lddo % 8 == 0 && ldo % 8 == 0) {
+            constexpr int QT = DT == 3 ? 4 : 2;
             size_t smem = (size_t)3 * 2 * RingImage<DT>::BYTES;
-            allow_big_smem(attn_bwd_dq_ring_kernel<DT, 4>, smem);
-            dim3 grid = attn_grid(P, (P.Nq + 255) / 256);
-            MC_LAUNCH((attn_bwd_dq_ring_kernel<DT, 4>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
+            allow_big_smem(attn_bwd_dq_ring_kernel<DT, QT>, smem);
+            dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
+            MC_LAUNCH((attn_bwd_dq_ring_kernel<DT, QT>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
             return;
         }
     }
@@ -1438,9 +1453,9 @@ static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t
 template <int DT>
 static void a_launch_dkdv(const AParams& P, const half_t* dO, int lddo, const float* lse, const float* Dbuf,
                           half_t* dk, int lddk, half_t* dv, int lddv, hipStream_t s) {
-    if constexpr (DT == 3) {
+    if constexpr (DT == 3 || DT == 5) {
         if (attn_bwd_ring_wanted(P) && lddo % 8 == 0) {
-            constexpr int KT = MC_ATTN_DKDV_KT;
+            constexpr int KT = DT == 3 ? MC_ATTN_DKDV_KT : 2;
             size_t smem = (size_t)3 * (2 * RingImage<DT>::BYTES + 2048);
             allow_big_smem(attn_bwd_dkdv_ring_kernel<DT, KT>, smem);
             dim3 grid = attn_grid(P, (P.Nk + 64 * KT - 1) / (64 * KT));

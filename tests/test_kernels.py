@@ -440,14 +440,15 @@ def test_attention_xcd_block_mapping_is_the_same_arithmetic(backend, monkeypatch
     close(_heads(mapped[0], nb, Nq, heads, d), ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ V, 1e-2, 1e-2, "attn fwd, XCD mapping")
 
 
+@pytest.mark.parametrize("d", [40, 80])
 @pytest.mark.parametrize("Nq,Nk,share", [(150, 150, 1), (70, 64, 1), (300, 77, 3), (64, 333, 1)])
-def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share):
-    """attention.hip attn_fwd_ring_kernel (d = 40 long sequences: LDS-DMA ring, transpose reads, 16-wide remainder step first):
+def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share, d):
+    """attention.hip attn_fwd_ring_kernel (d = 40 / 80 long sequences: LDS-DMA ring, transpose reads, softmax offset in a k-slot):
     one / several / ragged key tiles, ragged query blocks, keys shared by `share` batch entries.  On the emulator the kernel
     is forced at these small sizes (MC_ATTN_RING is re-read per call) and compared with the register-staged kernel as well;
     on the GPU the sizes are the ones that select it by default."""
     dev = backend
-    heads, d, nb = 2, 40, 2 * share
+    heads, nb = 2, 2 * share
     if big(dev):
         Nq, Nk, heads = Nq * 8 + 5, (Nk * 8 + 3 if Nk != 77 else 77 * 8), 8
     C = heads * d
@@ -469,13 +470,14 @@ def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share):
         close(lse, lse0, 1e-4, 1e-4, "ring vs register-staged lse")
 
 
+@pytest.mark.parametrize("d", [40, 80])
 @pytest.mark.parametrize("Nq,Nk,share", [(148, 148, 1), (64, 64, 1), (300, 77, 3)])
-def test_attention_backward_ring_kernels(backend, monkeypatch, Nq, Nk, share):
-    """attention.hip attn_bwd_dq_ring_kernel / attn_bwd_dkdv_ring_kernel (d = 40 long sequences): lse and D carried in padding
+def test_attention_backward_ring_kernels(backend, monkeypatch, Nq, Nk, share, d):
+    """attention.hip attn_bwd_dq_ring_kernel / attn_bwd_dkdv_ring_kernel (d = 40 / 80 long sequences): lse and D carried in padding
     k-slots of the dQ kernel's MFMAs, Q / dO / lse / D streamed by LDS-DMA in the dK / dV kernel.  Against autograd; ragged
     tiles on both axes; dq only with shared keys (cross-attention).  Forced at these sizes on the emulator, default on the GPU."""
     dev = backend
-    heads, d, nb = 2, 40, 2 * share
+    heads, nb = 2, 2 * share
     if big(dev):
         Nq, Nk, heads = Nq * 8 + 4, (Nk * 8 + 4 if Nk != 77 else 77 * 8), 8
         if share == 1:
