@@ -288,6 +288,78 @@ __global__ __launch_bounds__(256) void tattn_fwd_kernel(TParams P, half_t* o, in
     }
 }
 
+// ---- forward, attention output only, 16-byte loads (d % 8 == 0) --------------------------------------------------------------
+// The kernel above reads its operands 8 bytes per lane in DT steps and gathers V^T two bytes at a time (4 DT scalar loads per
+// lane): 18 load instructions for 3.75 KB per unit at d = 40, and it ran at 2.4 TB/s.  Here every operand row is read once,
+// 16 bytes per lane: the contraction index of the K = 32 MFMA is permuted so that lane group g's 8 k-slots of step s are the 8
+// adjacent head-dim elements [32 s + 8 g, +8) - 2 instructions per operand at d = 40, and 2 MFMAs per score tile instead of 3.
+// V goes through a wave-private row-major LDS image and comes back as V^T fragments by the hardware transpose read.
+template <int NT, int NS>
+__global__ __launch_bounds__(256) void tattn_fwd_vec_kernel(TParams P, half_t* o, int ldo) {
+    constexpr int PB = 64 * NS + 16;          // LDS row pitch, bytes (head dim padded to 32 NS)
+    constexpr int WAVE_LDS = 16 * NT * PB;
+    __shared__ __attribute__((aligned(16))) char vimg[4 * WAVE_LDS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int g = lane >> 4, c15 = lane & 15;
+    TUnit u = t_unit(P);
+    if (!u.live) return;  // whole wave
+    char* vl = vimg + wave * WAVE_LDS;
+    const int nch = P.d / 8;                  // 16-byte chunks per row
+    half8_t qf[NT][NS], kf[NT][NS];
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int f = 16 * t + c15;
+        const size_t row = t_row(P, u, f < P.F ? f : 0) * P.ld + u.h * P.d;
+#pragma unroll
+        for (int s2 = 0; s2 < NS; ++s2) {
+            const int ch = 4 * s2 + g;
+            const bool ok = f < P.F && ch < nch;
+            qf[t][s2] = ok ? ld8(P.q + row + 8 * ch) : zero8();
+            kf[t][s2] = ok ? ld8(P.k + row + 8 * ch) : zero8();
+            *reinterpret_cast<half8_t*>(vl + f * PB + 16 * ch) = ok ? ld8(P.v + row + 8 * ch) : zero8();
+        }
+    }
+    wave_lds_sync();
+    constexpr int DT = 2 * NS;                // 16-wide output tiles (those at / beyond d are skipped)
+#pragma unroll
+    for (int tq = 0; tq < NT; ++tq) {
+        f32x4 st[NT];
+#pragma unroll
+        for (int tk = 0; tk < NT; ++tk) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) st[tk] = mfma16k32(kf[tk][s2], qf[tq][s2], s2 == 0 ? fzero4() : st[tk]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) st[tk][i] = 16 * tk + 4 * g + i < P.F ? st[tk][i] * P.scale : -INFINITY;
+        }
+        float m, l;
+        t_softmax_T<NT>(st, m, l);
+        const float inv = 1.0f / l;
+        // P^T as the B operand; with two key tiles both go into ONE K = 32 step (k-slots 0-3: tile 0, 4-7: tile 1)
+        half8_t pf;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            pf[i] = (half_t)(st[0][i] * inv);
+            pf[4 + i] = NT == 2 ? (half_t)(st[NT - 1][i] * inv) : (half_t)0.f;
+        }
+        const int qrow = 16 * tq + c15;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            if (16 * dt >= P.d) break;   // uniform
+            // V^T[c = 16 dt + c15][f = 4 g + j (+ 16)]: lane passes &V[4 g + (c15 >> 2)][16 dt + 4 (c15 & 3)]
+            const half_t* vp = reinterpret_cast<const half_t*>(vl + (4 * g + (c15 >> 2)) * PB + 32 * dt + 8 * (c15 & 3));
+            const half8_t vf = cat4(lds_read_tr4(vp), NT == 2 ? lds_read_tr4(vp + 8 * PB) : zero4());
+            const f32x4 acc = mfma16k32(vf, pf, fzero4());
+            const int c = 16 * dt + 4 * g;
+            if (qrow < P.F && c < P.d) {
+                half4_t ov;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) ov[i] = to_half(acc[i]);
+                st4(o + t_row(P, u, qrow) * ldo + u.h * P.d + c, ov);
+            }
+        }
+    }
+}
+
 // ---- backward -------------------------------------------------------------------------------
 // inputs: q,k,v (P), dO (may be null), guidance seed (ref_idx/ref_val may be null, coef)
 // outputs: dq, dk, dv with row stride ldg (same token layout)
@@ -498,6 +570,15 @@ template <int NT, int DT>
 static void t_launch_fwd(const TParams& P, half_t* o, int ldo, int mode, half_t* tv, uint8_t* ti,
                          const uint8_t* ri, const float* rv, float* ul, hipStream_t s) {
     long units = (long)P.B * P.HW * P.heads;
+    if constexpr (DT == 3 || DT == 5 || DT == 10) {
+        // attention output, rows readable 16 bytes at a time (MC_TATTN_VEC=0: the 8-byte kernel, A/B)
+        static const int vec_env = getenv("MC_TATTN_VEC") ? atoi(getenv("MC_TATTN_VEC")) : 1;
+        const bool aligned = ((uintptr_t)P.q | (uintptr_t)P.k | (uintptr_t)P.v) % 16 == 0;
+        if (mode == 0 && vec_env && P.d % 8 == 0 && P.ld % 8 == 0 && aligned) {
+            MC_LAUNCH((tattn_fwd_vec_kernel<NT, (DT + 1) / 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, o, ldo);
+            return;
+        }
+    }
     MC_LAUNCH((tattn_fwd_kernel<NT, DT>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, o, ldo, mode, tv,
               ti, ri, rv, ul);
 }
