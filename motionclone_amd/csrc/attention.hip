@@ -1372,7 +1372,8 @@ static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipSt
         const int ring = attn_ring_env();
         // d = 40 / 80 exactly: the ring kernels need the padding k-slots of the 16-wide remainder step (and say which row of
         // V^T carries the denominators)
-        if (!P.causal && P.d == (DT == 3 ? 40 : 80) && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512))) {
+        // (any number of keys: the 77-key cross-attention gains 28 % as well - it is a stream over Q and O)
+        if (!P.causal && P.d == (DT == 3 ? 40 : 80) && (ring == 2 || (ring && P.Nq >= 1024))) {
             if constexpr (DT == 3) a_launch_fwd_ring<3, 4, true>(P, o, ldo, lse, s);
             else a_launch_fwd_ring<5, 2, false>(P, o, ldo, lse, s);
             return;
@@ -1427,7 +1428,7 @@ static int bwd_tiles(int rows, int dt) {
 static bool attn_bwd_ring_wanted(const AParams& P) {
     const int ring = attn_ring_env();
     // d = 40 / 80 exactly (padding k-slots); the D / lse chunks are fetched 16 bytes at a time
-    return (P.d == 40 || P.d == 80) && P.Nq % 4 == 0 && (ring == 2 || (ring && P.Nq >= 1024 && P.Nk >= 512));
+    return (P.d == 40 || P.d == 80) && P.Nq % 4 == 0 && (ring == 2 || (ring && P.Nq >= 1024));
 }
 template <int DT>
 static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t* dO, int lddo, const float* lse,

@@ -363,16 +363,28 @@ __global__ __launch_bounds__(256) void tattn_fwd_vec_kernel(TParams P, half_t* o
 // ---- backward -------------------------------------------------------------------------------
 // inputs: q,k,v (P), dO (may be null), guidance seed (ref_idx/ref_val may be null, coef)
 // outputs: dq, dk, dv with row stride ldg (same token layout)
-template <int NT, int DT, int VAR = 0>
+// VEC (round 3; d % 8 == 0, 16-byte aligned rows): every operand row is read ONCE, 16 bytes per lane (k-slot permutation of
+// tattn_fwd_vec_kernel: the K = 32 steps add the same products in the same order as the zero-extended K = 16 steps, bit for bit),
+// and Q, K, dO are kept as wave-private row-major LDS images from which the gradient MFMAs take their transposed fragments by
+// ds_read_b64_tr_b16 - 8 load instructions per unit at d = 40 instead of 48 (36 of them two-byte gathers).
+template <int NT, int DT, int VAR = 0, bool VEC = false>
 __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t* dO, int lddo, half_t* dq,
                                                          half_t* dk, half_t* dv, int ldg,
                                                          const uint8_t* ref_idx, const float* ref_val,
                                                          float seed_coef, float* dbg = nullptr) {
+    constexpr int NS = (DT + 1) / 2;
+    constexpr int PB = 64 * NS + 16;            // VEC: image row pitch, bytes
+    constexpr int IMG = 16 * NT * PB;           // one image of one wave
+    MC_DYN_SMEM(smem);
     const int lane = threadIdx.x & 63;
     const int g = lane >> 4, c15 = lane & 15;
     TUnit u = t_unit(P);
     if (!u.live) return;
     const long unit = ((long)u.b * P.HW + u.p) * P.heads + u.h;
+    char* img_q = smem + (threadIdx.x >> 6) * 3 * IMG;   // VEC: Q, K, dO rows of this unit
+    char* img_k = img_q + IMG;
+    char* img_o = img_k + IMG;
+    const int nch = P.d / 8;
 
     // S (q rows), S^T (kv rows), dP, dP^T accumulated over the head dimension
     f32x4 s[NT][NT], sT[NT][NT], dp[NT][NT], dpT[NT][NT];  // [tq][tk]
@@ -381,38 +393,87 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
 #pragma unroll
         for (int b = 0; b < NT; ++b) s[a][b] = sT[a][b] = dp[a][b] = dpT[a][b] = fzero4();
     // two passes over the head dimension, two accumulator chains each (scores, then dP)
+    if constexpr (VEC) {
 #pragma unroll
-    for (int ks = 0; ks < DT; ++ks) {
-        half4_t qf[NT], kf[NT];
-#pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            qf[t] = t_row_frag(P.q, P.ld, P, u, t, ks, lane);
-            kf[t] = t_row_frag(P.k, P.ld, P, u, t, ks, lane);
-        }
-#pragma unroll
-        for (int tq = 0; tq < NT; ++tq)
-#pragma unroll
-            for (int tk = 0; tk < NT; ++tk) {
-                s[tq][tk] = mfma16z(qf[tq], kf[tk], s[tq][tk]);    // [q = 4g+i][kv = c15]
-                sT[tq][tk] = mfma16z(kf[tk], qf[tq], sT[tq][tk]);  // [kv = 4g+i][q = c15]
-            }
-    }
-    if (dO) {
-#pragma unroll
-        for (int ks = 0; ks < DT; ++ks) {
-            half4_t vf[NT], of[NT];
+        for (int s2 = 0; s2 < NS; ++s2) {
+            half8_t qf[NT], kf[NT];
+            const int ch = 4 * s2 + g;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
-                vf[t] = t_row_frag(P.v, P.ld, P, u, t, ks, lane);
-                of[t] = t_row_frag(dO, lddo, P, u, t, ks, lane);
+                const int f = 16 * t + c15;
+                const bool ok = f < P.F && ch < nch;
+                const size_t row = t_row(P, u, f < P.F ? f : 0) * P.ld + u.h * P.d + 8 * ch;
+                qf[t] = ok ? ld8(P.q + row) : zero8();
+                kf[t] = ok ? ld8(P.k + row) : zero8();
+                *reinterpret_cast<half8_t*>(img_q + f * PB + 16 * ch) = qf[t];
+                *reinterpret_cast<half8_t*>(img_k + f * PB + 16 * ch) = kf[t];
             }
 #pragma unroll
             for (int tq = 0; tq < NT; ++tq)
 #pragma unroll
                 for (int tk = 0; tk < NT; ++tk) {
-                    dp[tq][tk] = mfma16z(of[tq], vf[tk], dp[tq][tk]);
-                    dpT[tq][tk] = mfma16z(vf[tk], of[tq], dpT[tq][tk]);
+                    s[tq][tk] = mfma16k32(qf[tq], kf[tk], s[tq][tk]);
+                    sT[tq][tk] = mfma16k32(kf[tk], qf[tq], sT[tq][tk]);
                 }
+        }
+        if (dO) {
+#pragma unroll
+            for (int s2 = 0; s2 < NS; ++s2) {
+                half8_t vf[NT], of[NT];
+                const int ch = 4 * s2 + g;
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const int f = 16 * t + c15;
+                    const bool ok = f < P.F && ch < nch;
+                    const size_t base = t_row(P, u, f < P.F ? f : 0);
+                    vf[t] = ok ? ld8(P.v + base * P.ld + u.h * P.d + 8 * ch) : zero8();
+                    of[t] = ok ? ld8(dO + base * lddo + u.h * P.d + 8 * ch) : zero8();
+                    *reinterpret_cast<half8_t*>(img_o + f * PB + 16 * ch) = of[t];
+                }
+#pragma unroll
+                for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+                    for (int tk = 0; tk < NT; ++tk) {
+                        dp[tq][tk] = mfma16k32(of[tq], vf[tk], dp[tq][tk]);
+                        dpT[tq][tk] = mfma16k32(vf[tk], of[tq], dpT[tq][tk]);
+                    }
+            }
+        }
+        wave_lds_sync();
+    } else {
+#pragma unroll
+        for (int ks = 0; ks < DT; ++ks) {
+            half4_t qf[NT], kf[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                qf[t] = t_row_frag(P.q, P.ld, P, u, t, ks, lane);
+                kf[t] = t_row_frag(P.k, P.ld, P, u, t, ks, lane);
+            }
+#pragma unroll
+            for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+                for (int tk = 0; tk < NT; ++tk) {
+                    s[tq][tk] = mfma16z(qf[tq], kf[tk], s[tq][tk]);    // [q = 4g+i][kv = c15]
+                    sT[tq][tk] = mfma16z(kf[tk], qf[tq], sT[tq][tk]);  // [kv = 4g+i][q = c15]
+                }
+        }
+        if (dO) {
+#pragma unroll
+            for (int ks = 0; ks < DT; ++ks) {
+                half4_t vf[NT], of[NT];
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    vf[t] = t_row_frag(P.v, P.ld, P, u, t, ks, lane);
+                    of[t] = t_row_frag(dO, lddo, P, u, t, ks, lane);
+                }
+#pragma unroll
+                for (int tq = 0; tq < NT; ++tq)
+#pragma unroll
+                    for (int tk = 0; tk < NT; ++tk) {
+                        dp[tq][tk] = mfma16z(of[tq], vf[tk], dp[tq][tk]);
+                        dpT[tq][tk] = mfma16z(vf[tk], of[tq], dpT[tq][tk]);
+                    }
+            }
         }
     }
 
@@ -521,9 +582,21 @@ __global__ __launch_bounds__(256) void tattn_bwd_kernel(TParams P, const half_t*
         half4_t kc[NT], qc[NT], oc[NT];
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
-            kc[t] = t_col_frag(P.k, P.ld, P, u, t, dt, lane);
-            qc[t] = t_col_frag(P.q, P.ld, P, u, t, dt, lane);
-            if (dO) oc[t] = t_col_frag(dO, lddo, P, u, t, dt, lane);
+            if constexpr (VEC) {
+                // X^T[c = 16 dt + c15][f = 16 t + 4 g + j]: the lane passes &X[16 t + 4 g + (c15 >> 2)][16 dt + 4 (c15 & 3)]
+                if (16 * dt < P.d) {   // uniform (tiles at / beyond d have no image columns when d % 32 == 0)
+                    const int off = (16 * t + 4 * g + (c15 >> 2)) * PB + 32 * dt + 8 * (c15 & 3);
+                    kc[t] = lds_read_tr4(reinterpret_cast<const half_t*>(img_k + off));
+                    qc[t] = lds_read_tr4(reinterpret_cast<const half_t*>(img_q + off));
+                    if (dO) oc[t] = lds_read_tr4(reinterpret_cast<const half_t*>(img_o + off));
+                } else {
+                    kc[t] = qc[t] = oc[t] = zero4();
+                }
+            } else {
+                kc[t] = t_col_frag(P.k, P.ld, P, u, t, dt, lane);
+                qc[t] = t_col_frag(P.q, P.ld, P, u, t, dt, lane);
+                if (dO) oc[t] = t_col_frag(dO, lddo, P, u, t, dt, lane);
+            }
         }
 #pragma unroll
         for (int t = 0; t < NT; ++t) {
@@ -590,6 +663,19 @@ static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* d
         if (g_tattn_debug_buf) {
             MC_LAUNCH((tattn_bwd_kernel<NT, DT, 1>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
                       dq, dk, dv, ldg, ri, rv, coef, g_tattn_debug_buf);
+            return;
+        }
+    }
+    if constexpr (DT == 3 || DT == 5 || DT == 10) {
+        static const int vec_env = getenv("MC_TATTN_VEC") ? atoi(getenv("MC_TATTN_VEC")) : 1;
+        const bool aligned = ((uintptr_t)P.q | (uintptr_t)P.k | (uintptr_t)P.v | (uintptr_t)dO) % 16 == 0;
+        constexpr int NS = (DT + 1) / 2;
+        constexpr size_t smem = (size_t)4 * 3 * 16 * NT * (64 * NS + 16);
+        // (images of at most 48 KiB per workgroup: F <= 16 at d = 40 / 80; beyond that the occupancy lost costs more)
+        if (smem <= 48 * 1024 && vec_env && P.d % 8 == 0 && P.ld % 8 == 0 && (!dO || lddo % 8 == 0) && aligned) {
+            allow_big_smem(tattn_bwd_kernel<NT, DT, 0, true>, smem);
+            MC_LAUNCH((tattn_bwd_kernel<NT, DT, 0, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), smem, s, P, dO, lddo,
+                      dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
             return;
         }
     }

@@ -42,3 +42,20 @@ for frames in (16, 32):
                                                                           dk=dqkv[:, C:2 * C], dv=dqkv[:, 2 * C:]), iters=10)
         print(json.dumps(dict(cfg=tag, level=name, frames=frames, fwd_ms=round(ms, 4), fwd_tflops=round(fl / ms / 1e9, 1),
                               bwd_ms=round(msb, 4), bwd_tflops=round(2.5 * fl / msb / 1e9, 1))), flush=True)
+
+# cross-attention (77 text keys shared by the 16 frames of a video): forward + dQ
+for frames in (16, 32):
+    for (name, N, d) in [("x0", 4096, 40), ("x1", 1024, 80), ("x2", 256, 160)]:
+        C = 8 * d
+        q = (torch.randn(frames * N, C, device=dev) * 0.5).half()
+        kv = (torch.randn(frames // 16 * 77, 2 * C, device=dev) * 0.5).half()
+        k, v = kv[:, :C], kv[:, C:]
+        ms = timeit(lambda: ops.attn_fwd(q, k, v, N, 77, 8, d, frames, kv_bdiv=16))
+        o, lse = ops.attn_fwd(q, k, v, N, 77, 8, d, frames, kv_bdiv=16)
+        do = (torch.randn(frames * N, C, device=dev)).half()
+        dq = torch.empty_like(q)
+        msb = float("nan") if fwd_only else timeit(lambda: ops.attn_bwd(q, k, v, o, do, lse, N, 77, 8, d, frames, kv_bdiv=16,
+                                                                          dq=dq, need_dkv=False), iters=10)
+        gb = 4.0 * frames * N * C   # q in, o out
+        print(json.dumps(dict(cfg=tag, level=name, frames=frames, fwd_ms=round(ms, 4), fwd_gbps=round(gb / ms / 1e6, 1),
+                              bwd_ms=round(msb, 4), bwd_gbps=round(2 * gb / msb / 1e6, 1))), flush=True)

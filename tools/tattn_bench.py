@@ -35,4 +35,8 @@ for B in (1, 2):
         out = torch.empty(B * F * HW, C, device=dev, dtype=torch.float16)
         ms = timeit(lambda: ops.tattn_fwd(q, k, v, B, F, HW, 8, d, out=out))
         nbytes = 8.0 * B * F * HW * C
-        print(json.dumps(dict(vec=tag, level=name, B=B, fwd_us=round(1e3 * ms, 2), fwd_gbps=round(nbytes / ms / 1e6, 1))), flush=True)
+        do = torch.randn(B * F * HW, C, device=dev).half()
+        dqkv = torch.empty_like(qkv)
+        msb = timeit(lambda: ops.tattn_bwd(q, k, v, do, dqkv[:, :C], dqkv[:, C:2 * C], dqkv[:, 2 * C:], B, F, HW, 8, d))
+        print(json.dumps(dict(vec=tag, level=name, B=B, fwd_us=round(1e3 * ms, 2), fwd_gbps=round(nbytes / ms / 1e6, 1),
+                              bwd_us=round(1e3 * msb, 2), bwd_gbps=round(14.0 / 8.0 * nbytes / msb / 1e6, 1))), flush=True)
