@@ -413,7 +413,7 @@ constexpr float kRebase = 8.0f;   // re-base a row's offset when 2^(score - offs
 // PADROW: the head dim leaves a padding row in V^T (d = 40) that becomes the ones row; otherwise (d = 80) the denominators take
 // one more output tile whose V^T fragment is a constant (row 0 = ones): two more MFMAs per query tile instead of 16 adds.
 template <int DT, int QT, bool PADROW>
-__global__ __launch_bounds__(256, 2) void attn_fwd_ring_kernel(AParams P, half_t* o, int ldo, float* lse) {
+__global__ __launch_bounds__(256, (DT == 3 && QT == 2) ? 4 : 2) void attn_fwd_ring_kernel(AParams P, half_t* o, int ldo, float* lse) {
     constexpr int DTO = DT + (PADROW ? 0 : 1);   // output tiles incl. the denominators' row
     constexpr int CPR = 2 * DT;          // 16-byte chunks per image row
     constexpr int PB = 32 * DT;          // row pitch, bytes
@@ -1374,8 +1374,14 @@ static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipSt
         // V^T carries the denominators)
         // (any number of keys: the 77-key cross-attention gains 28 % as well - it is a stream over Q and O)
         if (!P.causal && P.d == (DT == 3 ? 40 : 80) && (ring == 2 || (ring && P.Nq >= 1024))) {
-            if constexpr (DT == 3) a_launch_fwd_ring<3, 4, true>(P, o, ldo, lse, s);
-            else a_launch_fwd_ring<5, 2, false>(P, o, ldo, lse, s);
+            if constexpr (DT == 3) {
+                // MC_ATTN_QT=2: 32 rows per wave, 122 registers, four workgroups per CU - A/B only: 3-9 % SLOWER than 64 rows per wave
+                // at two workgroups per CU (profiles/r03_attn_qt_ab.jsonl): twice the LDS fragment reads and DMA issue per score
+                if (qt_env == 2) a_launch_fwd_ring<3, 2, true>(P, o, ldo, lse, s);
+                else a_launch_fwd_ring<3, 4, true>(P, o, ldo, lse, s);
+            } else {
+                a_launch_fwd_ring<5, 2, false>(P, o, ldo, lse, s);
+            }
             return;
         }
     }
