@@ -95,6 +95,12 @@ int mc_groupnorm_stats_f16(const void* a, const void* b, int lda, int ldb, int c
 int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
                            const float* stats, const float* gamma, const float* beta, void* out, int ldo,
                            int silu, void* stream);
+/* statistics + normalisation (+ SiLU) of one GroupNorm in two launches (partial sums; apply, which finalises the statistics in
+ * its prologue and writes them to `stats` for the backward): the results of mc_groupnorm_stats_f16 followed by
+ * mc_groupnorm_apply_f16, without the finalize launch between them. */
+int mc_groupnorm_fwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw, float eps,
+                         float* partial, float* stats, const float* gamma, const float* beta, void* out, int ldo, int silu,
+                         void* stream);
 /* data-gradient (autograd of the above; reference motionclone_functions.py:236). bstats: float[frames*64] */
 int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
                          const void* dz, int lddz, const float* stats, const float* gamma, const float* beta,

@@ -126,16 +126,58 @@ __global__ void gn_finalize_kernel(const float* partial, float* stats, int frame
     }
 }
 
+// Round 3: the finalize pass INSIDE its consumers.  The 64 group totals of this block's frame are summed from the per-chunk
+// partials by 64 threads (chunk order 0 .. nchunk-1, the order gn_finalize_kernel uses: bit-identical statistics) and turned into
+// (mean, rstd) [mode 0] or (s1 / n, s2 / n) [mode 1] in LDS; chunk 0 of every frame also writes them to `stats_out` (the backward
+// and the C ABI's stats tensor).  One launch less per GroupNorm (3.5 k launches per video).
+__device__ __forceinline__ void gn_block_stats(const float* partial, int frame, int nchunk, float n, float eps, int mode,
+                                               float* lds /* [64] */, float* stats_out, bool write) {
+    const int t = threadIdx.x;
+    if (t < 64) {
+        const float* q = partial + (size_t)frame * nchunk * 64 + t;
+        float a = 0.f;
+        for (int c = 0; c < nchunk; ++c) a += q[(size_t)c * 64];
+        lds[t] = a;
+    }
+    __syncthreads();
+    float r0 = 0.f, r1 = 0.f;
+    if (t < 32) {
+        const float a = lds[2 * t], b = lds[2 * t + 1];
+        if (mode == 0) {
+            const float mean = a / n;
+            const float var = fmaxf(b / n - mean * mean, 0.f);
+            r0 = mean;
+            r1 = 1.0f / sqrtf(var + eps);
+        } else {
+            r0 = a / n;
+            r1 = b / n;
+        }
+    }
+    __syncthreads();
+    if (t < 32) {
+        lds[2 * t] = r0;
+        lds[2 * t + 1] = r1;
+        if (write) {
+            stats_out[((size_t)frame * 32 + t) * 2] = r0;
+            stats_out[((size_t)frame * 32 + t) * 2 + 1] = r1;
+        }
+    }
+    __syncthreads();
+}
+
 // y = (x - mean) * rstd * gamma + beta, optional SiLU; out is [tokens][ctot] (ld = ldo).
 // grid (nchunk, frames), block = VC * R threads: a thread owns one 8-channel vector column for the whole chunk, so
 // the per-channel scale / shift (rstd*gamma, beta - mean*rstd*gamma) are computed once and live in registers.
-__global__ void gn_apply_kernel(GnSrc s, const float* stats, const float* gamma, const float* beta,
-                                half_t* out, int ldo, int R, int nchunk, int silu) {
+// partial != nullptr: the statistics come from the per-chunk partials (gn_block_stats) and `stats` is an OUTPUT.
+__global__ void gn_apply_kernel(GnSrc s, float* stats, const float* gamma, const float* beta,
+                                half_t* out, int ldo, int R, int nchunk, int silu, const float* partial, float n, float eps) {
+    __shared__ float bst[64];
     const int VC = s.ctot / 8;
     const int t = threadIdx.x;
     const int col = t % VC, r = t / VC;
-    if (r >= R) return;
     const int frame = blockIdx.y, chunk = blockIdx.x;
+    if (partial) gn_block_stats(partial, frame, nchunk, n, eps, 0, bst, stats, chunk == 0);
+    if (r >= R) return;
     const int per = (s.hw + nchunk - 1) / nchunk;
     const int t0 = chunk * per;
     const int t1 = min(s.hw, t0 + per);
@@ -143,7 +185,7 @@ __global__ void gn_apply_kernel(GnSrc s, const float* stats, const float* gamma,
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         int c = col * 8 + e;
-        const float* st = stats + ((size_t)frame * 32 + c / s.cpg) * 2;
+        const float* st = partial ? bst + (c / s.cpg) * 2 : stats + ((size_t)frame * 32 + c / s.cpg) * 2;
         sc[e] = st[1] * gamma[c];
         sh[e] = beta[c] - st[0] * sc[e];
     }
@@ -215,14 +257,17 @@ __global__ void gn_bwd_partial_kernel(GnSrc s, const half_t* dz, int lddz, const
 
 // dx = rstd * (dxhat - mean(dxhat) - xhat * mean(dxhat*xhat)); optional accumulate into dx.  Same thread layout
 // as gn_apply_kernel (per-channel constants in registers).
+// (the group means of dxhat and dxhat * xhat come from the per-chunk partials of pass 1: gn_block_stats, mode 1)
 __global__ void gn_bwd_apply_kernel(GnSrc s, const half_t* dz, int lddz, const float* stats,
-                                    const float* bstats, const float* gamma, const float* beta, int silu,
-                                    half_t* dx, int lddx, int R, int nchunk, int accumulate) {
+                                    float* bstats_out, const float* gamma, const float* beta, int silu,
+                                    half_t* dx, int lddx, int R, int nchunk, int accumulate, const float* partial, float n) {
+    __shared__ float bstats[64];
     const int VC = s.ctot / 8;
     const int t = threadIdx.x;
     const int col = t % VC, r = t / VC;
-    if (r >= R) return;
     const int frame = blockIdx.y, chunk = blockIdx.x;
+    gn_block_stats(partial, frame, nchunk, n, 0.f, 1, bstats, bstats_out, chunk == 0);
+    if (r >= R) return;
     const int per = (s.hw + nchunk - 1) / nchunk;
     const int t0 = chunk * per;
     const int t1 = min(s.hw, t0 + per);
@@ -233,8 +278,8 @@ __global__ void gn_bwd_apply_kernel(GnSrc s, const half_t* dz, int lddz, const f
         size_t gi = ((size_t)frame * 32 + c / s.cpg) * 2;
         mean[e] = stats[gi];
         rstd[e] = stats[gi + 1];
-        m1[e] = bstats[gi];
-        m2[e] = bstats[gi + 1];
+        m1[e] = bstats[(c / s.cpg) * 2];
+        m2[e] = bstats[(c / s.cpg) * 2 + 1];
         gm[e] = gamma[c];
         bt[e] = beta[c];
     }
@@ -556,8 +601,26 @@ extern "C" int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int
     int R, threads;
     if (!gn_geometry(ctot, &R, &threads)) return MC_ERR_UNSUPPORTED;
     int nchunk = mc_gn_nchunk(hw);
+    MC_LAUNCH(gn_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, const_cast<float*>(stats), gamma,
+              beta, (half_t*)out, ldo, R, nchunk, silu, (const float*)nullptr, 0.f, 0.f);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// statistics + normalisation (+ SiLU) of one GroupNorm in TWO launches: per-chunk partial sums, then the apply pass, which
+// finalises the statistics in its prologue and writes them to `stats` (float[frames*32*2], for the backward).  Same results as
+// mc_groupnorm_stats_f16 followed by mc_groupnorm_apply_f16, bit for bit.  workspace: partial as for mc_groupnorm_stats_f16.
+extern "C" int mc_groupnorm_fwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
+                                    float eps, float* partial, float* stats, const float* gamma, const float* beta,
+                                    void* out, int ldo, int silu, void* stream) {
+    GnSrc s;
+    if (!make_src(&s, a, b, lda, ldb, c1, ctot, hw) || frames <= 0 || hw <= 0 || ldo % 8) return MC_ERR_SHAPE;
+    int R, threads;
+    if (!gn_geometry(ctot, &R, &threads) || threads < 64) return MC_ERR_UNSUPPORTED;
+    int nchunk = mc_gn_nchunk(hw);
+    size_t smem = (size_t)2 * R * ctot * sizeof(float);
+    MC_LAUNCH(gn_partial_kernel, dim3(nchunk, frames), dim3(threads), smem, (hipStream_t)stream, s, R, nchunk, partial);
     MC_LAUNCH(gn_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, stats, gamma, beta,
-              (half_t*)out, ldo, R, nchunk, silu);
+              (half_t*)out, ldo, R, nchunk, silu, (const float*)partial, (float)hw * s.cpg, eps);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
@@ -574,11 +637,10 @@ extern "C" int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int l
     size_t smem = (size_t)2 * R * ctot * sizeof(float);
     MC_LAUNCH(gn_bwd_partial_kernel, dim3(nchunk, frames), dim3(threads), smem, (hipStream_t)stream, s,
               (const half_t*)dz, lddz, stats, gamma, beta, silu, R, nchunk, partial);
-    int n = frames * 32;
-    MC_LAUNCH(gn_finalize_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
-              (const float*)partial, bstats, frames, nchunk, (float)hw * s.cpg, 0.f, 1);
+    if (threads < 64) return MC_ERR_UNSUPPORTED;
     MC_LAUNCH(gn_bwd_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, (const half_t*)dz,
-              lddz, stats, (const float*)bstats, gamma, beta, silu, (half_t*)dx, lddx, R, nchunk, accumulate);
+              lddz, stats, bstats, gamma, beta, silu, (half_t*)dx, lddx, R, nchunk, accumulate, (const float*)partial,
+              (float)hw * s.cpg);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 

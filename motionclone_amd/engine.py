@@ -268,13 +268,11 @@ class UNet3DEngine:
             tb, rpb = tb.contiguous(), geo.F * hw
         g1w, b1 = w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias")
         g2, b2 = w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias")
-        st1 = ops.gn_stats(x, x2, fr, hw, eps)
-        h1 = ops.gn_apply(x, x2, st1, g1w, b1, True, fr, hw)
+        h1, st1 = ops.gn_fwd(x, x2, g1w, b1, True, fr, hw, eps)
         h2 = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=rpb, mode=CONV_S1,
                       geom=(H, W, H, W), m_out=geo.T)
         del h1
-        st2 = ops.gn_stats(h2, None, fr, hw, eps)
-        h3 = ops.gn_apply(h2, None, st2, g2, b2, True, fr, hw)
+        h3, st2 = ops.gn_fwd(h2, None, g2, b2, True, fr, hw, eps)
         has_sc = (p + "conv_shortcut.weight") in w.sd
         if has_sc:
             sc = ops.gemm(x, w.lin(p + "conv_shortcut.weight"), a2=x2,
@@ -319,8 +317,7 @@ class UNet3DEngine:
         fr, hw, T = geo.frames, geo.hw, geo.T
         b = p + "transformer_blocks.0."
         gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
-        st = ops.gn_stats(x, None, fr, hw, 1e-6)
-        hn = ops.gn_apply(x, None, st, gN, bN, False, fr, hw)
+        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6)
         h0 = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
         del hn
         # self-attention
@@ -400,8 +397,7 @@ class UNet3DEngine:
         b = p + "transformer_blocks.0."
         gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
         pe = w.pe(C)[:geo.F].contiguous()
-        st = ops.gn_stats(x, None, fr, hw, 1e-6)
-        hn = ops.gn_apply(x, None, st, gN, bN, False, fr, hw)
+        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6)
         h = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
         del hn
         saved = []
@@ -593,8 +589,7 @@ class UNet3DEngine:
             if i < 3:
                 # the upsampler of block i feeds block i+1: in the graph only while i+1 <= guidance block
                 x, geo = self._upsample("up_blocks.%d.upsamplers.0.conv." % i, x, geo, tape if i < gb else None)
-        st = ops.gn_stats(x, None, geo.frames, geo.hw, cfg["norm_eps"])
-        hn = ops.gn_apply(x, None, st, w.vec("conv_norm_out.weight"), w.vec("conv_norm_out.bias"), True, geo.frames, geo.hw)
+        hn, st = ops.gn_fwd(x, None, w.vec("conv_norm_out.weight"), w.vec("conv_norm_out.bias"), True, geo.frames, geo.hw, cfg["norm_eps"])
         eps = ops.gemm(hn, w.conv("conv_out.weight"), bias=w.vec("conv_out.bias").unsqueeze(0), mode=CONV_S1,
                        geom=(geo.H, geo.W, geo.H, geo.W), m_out=geo.T)
         return eps

@@ -42,6 +42,7 @@ SIGNATURES = {
     "mc_gn_nchunk": [I],
     "mc_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, F, P, P, P],
     "mc_groupnorm_apply_f16": [P, P, I, I, I, I, I, I, P, P, P, P, I, I, P],
+    "mc_groupnorm_fwd_f16": [P, P, I, I, I, I, I, I, F, P, P, P, P, P, I, I, P],
     "mc_groupnorm_bwd_f16": [P, P, I, I, I, I, I, I, P, I, P, P, P, I, P, P, P, I, I, P],
     "mc_layernorm_fwd_f16": [P, I, P, I, P, P, P, I, I, P, I, I, F, P],
     "mc_layernorm_bwd_f16": [P, I, P, I, P, P, P, I, P, I, I, I, P],

@@ -181,6 +181,20 @@ def gn_apply(x, x2, stats, gamma, beta, silu, frames, hw, out=None):
     return out
 
 
+def gn_fwd(x, x2, gamma, beta, silu, frames, hw, eps, out=None):
+    """GroupNorm(32) (+ SiLU) of [frames * hw, c1 (+ c2)] tokens -> (out, stats); stats = (mean, rstd) per (frame, group) for
+    the backward.  gn_stats + gn_apply without the finalize launch (mc_groupnorm_fwd_f16)."""
+    c1 = x.shape[1]
+    ctot = c1 + (x2.shape[1] if x2 is not None else 0)
+    partial = workspace("groupnorm", x, frames, hw)
+    stats = empty((frames, 32, 2), x, torch.float32)
+    if out is None:
+        out = empty((frames * hw, ctot), x)
+    lib.call("mc_groupnorm_fwd_f16", _p(x), _p(x2), _ld(x), _ld(x2), c1, ctot, frames, hw, float(eps), _p(partial),
+             _p(stats), _p(_f32(gamma)), _p(_f32(beta)), _p(out), _ld(out), int(silu), _stream(x))
+    return out, stats
+
+
 def gn_bwd(x, x2, dz, stats, gamma, beta, silu, frames, hw, out=None, accumulate=False):
     c1 = x.shape[1]
     ctot = c1 + (x2.shape[1] if x2 is not None else 0)

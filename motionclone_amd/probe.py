@@ -67,6 +67,9 @@ def _cost(name, a):
     if name == "mc_groupnorm_apply_f16":
         ctot, frames, hw = a[5], a[6], a[7]
         return ("groupnorm_apply", 0.0, 4.0 * frames * hw * ctot, (frames * hw, ctot))
+    if name == "mc_groupnorm_fwd_f16":
+        ctot, frames, hw = a[5], a[6], a[7]
+        return ("groupnorm_fwd", 0.0, 6.0 * frames * hw * ctot, (frames * hw, ctot))
     if name == "mc_groupnorm_bwd_f16":
         ctot, frames, hw = a[5], a[6], a[7]
         return ("groupnorm_bwd", 0.0, (8.0 if a[18] else 6.0) * frames * hw * ctot, (frames * hw, ctot))

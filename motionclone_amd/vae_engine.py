@@ -45,12 +45,10 @@ class VaeBlocks:
     def _resnet(self, p, x, n, H, W):
         """ResnetBlock2D without time embedding (diffusers 0.16.0 models/resnet.py)"""
         w, hw, T = self.w, H * W, n * H * W
-        st1 = ops.gn_stats(x, None, n, hw, EPS)
-        h = ops.gn_apply(x, None, st1, w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias"), True, n, hw)
+        h, st1 = ops.gn_fwd(x, None, w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias"), True, n, hw, EPS)
         h = ops.gemm(h, w.conv(p + "conv1.weight"), bias=w.vec(p + "conv1.bias").unsqueeze(0), mode=CONV_S1,
                      geom=(H, W, H, W), m_out=T)
-        st2 = ops.gn_stats(h, None, n, hw, EPS)
-        h2 = ops.gn_apply(h, None, st2, w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias"), True, n, hw)
+        h2, st2 = ops.gn_fwd(h, None, w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias"), True, n, hw, EPS)
         del h
         if (p + "conv_shortcut.weight") in w.sd:
             x = ops.gemm(x, w.lin(p + "conv_shortcut.weight"), bias=w.vec(p + "conv_shortcut.bias").unsqueeze(0))
@@ -63,8 +61,7 @@ class VaeBlocks:
         C = x.shape[1]
         if hw % 64:
             raise NotImplementedError("VAE attention needs a multiple of 64 latent pixels per frame (got %d)" % hw)
-        st = ops.gn_stats(x, None, n, hw, EPS)
-        nx = ops.gn_apply(x, None, st, w.vec(p + "group_norm.weight"), w.vec(p + "group_norm.bias"), False, n, hw)
+        nx, st = ops.gn_fwd(x, None, w.vec(p + "group_norm.weight"), w.vec(p + "group_norm.bias"), False, n, hw, EPS)
         q = ops.gemm(nx, w.lin(p + "query.weight"), bias=w.vec(p + "query.bias").unsqueeze(0))
         k = ops.gemm(nx, w.lin(p + "key.weight"), bias=w.vec(p + "key.bias").unsqueeze(0))
         o = ops.empty((n * hw, C), x)

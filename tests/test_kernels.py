@@ -323,6 +323,10 @@ def test_groupnorm_fwd_bwd(backend, C1, C2, silu):
     if silu:
         ref = Fn.silu(ref)
     close(_from_cl(y, NF, H, W), ref, 1e-2, 5e-3, "gn fwd")
+    # the two-launch form the engine uses (statistics finalised in the apply pass's prologue): the same output and statistics
+    y2, stats2 = ops.gn_fwd(xa, xb, gamma, beta, silu, NF, H * W, 1e-5)
+    assert torch.equal(y2, y), "mc_groupnorm_fwd_f16 differs from stats + apply"
+    assert torch.equal(stats2, stats), "mc_groupnorm_fwd_f16 leaves different statistics"
     dz = rnd((NF, C, H, W), dev, 4)
     (dref,) = torch.autograd.grad(ref, xr, dz.float())
     dx = ops.gn_bwd(xa, xb, _to_cl(dz), stats, gamma, beta, silu, NF, H * W)
