@@ -12,6 +12,7 @@ echo "trace a rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_r03_b -- python bench.py --no-cpu-baseline --no-vae --no-graphs --inflight 1 --steps 2 > gpurun_out/prof_r03_b/bench.json 2> gpurun_out/prof_r03_b/bench.err
 echo "trace b rc=$?"
 find gpurun_out/prof_r03_a gpurun_out/prof_r03_b -name "*kernel_trace.csv" -delete
+python tools/kernel_stats_md.py gpurun_out/prof_r03_a gpurun_out/prof_r03_b gpurun_out/r03_kernel_stats.md "round-3"
 cut -c1-200 gpurun_out/prof_r03_a/bench.json; echo; cut -c1-200 gpurun_out/prof_r03_b/bench.json; echo
 timeout 600 python bench.py --no-cpu-baseline --no-vae --frames 16 --size 256 --ddim-steps 10 --guided-steps 5 --guidance-scale 0.3 --steps 16 --warmup 8 --inflight 8 > gpurun_out/r03_bench_cfg1.json 2> gpurun_out/r03_bench_cfg1.err
 timeout 600 python bench.py --no-cpu-baseline --no-vae --sparsectrl --guided-steps 12 --guidance-scale 0.3 --steps 6 --warmup 3 > gpurun_out/r03_bench_cfg4.json 2> gpurun_out/r03_bench_cfg4.err

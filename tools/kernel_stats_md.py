@@ -1,0 +1,77 @@
+"""rocprofv3 --kernel-trace --stats CSVs of tools/gpu_profile_*_final.sh -> profiles/<round>_kernel_stats.md (+ the two CSVs).
+usage: python tools/kernel_stats_md.py <prof_a dir> <prof_b dir> <out md> <round tag> [videos_a videos_b]"""
+import csv
+import glob
+import json
+import os
+import re
+import shutil
+import sys
+
+
+def stats_csv(d):
+    fs = glob.glob(os.path.join(d, "**", "*kernel_stats.csv"), recursive=True)
+    assert fs, "no kernel_stats.csv under " + d
+    return max(fs, key=os.path.getsize)
+
+
+def short(name):
+    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"\(.*$", "", name)
+    name = name.replace("mc::", "")
+    name = re.sub(r"^_ZN2mc", "", name)
+    return name[:72]
+
+
+def bench_value(d):
+    try:
+        lines = [l for l in open(os.path.join(d, "bench.json")) if l.startswith("{")]
+        return json.loads(lines[-1])["value"]
+    except Exception:
+        return None
+
+
+def table(path, videos, top=34):
+    rows = list(csv.DictReader(open(path)))
+    ncalls = sum(int(r["Calls"]) for r in rows)
+    tot = sum(int(r["TotalDurationNs"]) for r in rows) / 1e9
+    mine = [r for r in rows if "mc::" in r["Name"] or "_ZN2mc" in r["Name"]]
+    out = ["| kernel | calls | calls / video | total ms | avg us | % |", "|---|---|---|---|---|---|"]
+    for r in rows[:top]:
+        out.append("| `%s` | %d | %d | %.1f | %.1f | %s |" % (short(r["Name"]), int(r["Calls"]), round(int(r["Calls"]) / videos),
+                                                          int(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, r["Percentage"]))
+    return ncalls, tot, sum(int(r["Calls"]) for r in mine), "\n".join(out)
+
+
+a_dir, b_dir, out_md, tag = sys.argv[1:5]
+va = int(sys.argv[5]) if len(sys.argv) > 5 else 10   # 3 warm-up + 3 timed + 4 eager (probe pass)
+vb = int(sys.argv[6]) if len(sys.argv) > 6 else 7    # 1 warm-up + 2 timed + 4 eager
+pa, pb = stats_csv(a_dir), stats_csv(b_dir)
+base = out_md[:-3]
+shutil.copy(pa, base + "_a.csv")
+shutil.copy(pb, base + "_b.csv")
+na, ta, ma, tab_a = table(pa, va)
+nb, tb, mb, tab_b = table(pb, vb)
+md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
+
+`tools/gpu_profile_r03_final.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
+timed, and the four eager videos of the bench's probe pass).  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM>` (MODE 0 dense, 1
+conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU), `gemm4_kernel<20, GEGLU>` = K = 320 streaming kernel,
+`attn_*_ring_kernel<DT, rows/16 per wave>` = the LDS-DMA ring attention (DT 3: d = 40, 5: d = 80).
+
+## (a) DEFAULT command `python bench.py --no-cpu-baseline --no-vae --steps 3`: hipGraph replay, three videos in flight (kernel durations are measured while kernels of the other two videos share the CUs)
+
+Bench line of this run: **%s videos/min** (under the profiler); videos in the trace: 3 warm-up + 3 timed + 4 eager = **%d**; %d kernel launches
+= **%d per video** (%d of them this library's); total kernel time %.1f s.
+
+%s
+
+## (b) `--no-graphs --inflight 1 --steps 2`: one video at a time on the eager launch sequence (the regime of the roofline probe of bench.py)
+
+Bench line of this run: **%s videos/min**; videos in the trace: 1 warm-up + 2 timed + 4 eager = **%d**; %d kernel launches = **%d per video**;
+total kernel time %.1f s = %.2f s per video.
+
+%s
+""" % (tag, bench_value(a_dir), va, na, round(na / va), round(ma / va), ta, tab_a, bench_value(b_dir), vb, nb, round(nb / vb), tb, tb / vb, tab_b)
+open(out_md, "w").write(md)
+print(out_md, "launches per video:", round(na / va), round(nb / vb))
