@@ -134,9 +134,18 @@ __device__ __forceinline__ void gn_block_stats(const float* partial, int frame, 
                                                float* lds /* [64] */, float* stats_out, bool write) {
     const int t = threadIdx.x;
     if (t < 64) {
+        // same order of additions as the finalize kernel, but eight loads in flight (the chunk loop is pure L2 latency)
         const float* q = partial + (size_t)frame * nchunk * 64 + t;
         float a = 0.f;
-        for (int c = 0; c < nchunk; ++c) a += q[(size_t)c * 64];
+        int c = 0;
+        for (; c + 8 <= nchunk; c += 8) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(c + u) * 64];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += v[u];
+        }
+        for (; c < nchunk; ++c) a += q[(size_t)c * 64];
         lds[t] = a;
     }
     __syncthreads();

@@ -255,6 +255,30 @@ class UNet3DEngine:
             return t[b * per:(b + 1) * per]
         return Geo(1, geo.F, geo.H, geo.W), cut
 
+    def _ff_geglu(self, n, prefix, geo, tape):
+        """FeedForward's first Linear + GEGLU on the normalised rows `n` -> (h * gelu(gate), taped pre-activation or None).
+        No backward: the product is formed in the GEMM epilogue and the [T, 8C] pre-activation never exists.  With a tape only
+        the differentiated batch element needs it: its rows take the unfused Linear + geglu kernel, the rows of the other batch
+        element (the unconditional half of a guided step) stay on the fused epilogue - half the geglu launches' bytes and
+        a third of that GEMM's output traffic gone."""
+        w = self.w
+        wname, bname = prefix + "ff.net.0.proj.weight", prefix + "ff.net.0.proj.bias"
+        if tape is None:
+            return ops.gemm(n, w.geglu_lin(wname), bias=w.geglu_vec(bname), geglu=True), None
+        gb = tape.grad_batch
+        if gb is None or geo.B == 1:
+            ff1 = ops.gemm(n, w.lin(wname), bias=w.vec(bname).unsqueeze(0))
+            return ops.geglu_fwd(ff1), ff1
+        T1 = geo.T // geo.B
+        gg = ops.empty((geo.T, w.lin(wname).shape[0] // 2), n)
+        lo, hi = gb * T1, (gb + 1) * T1
+        ff1 = ops.gemm(n[lo:hi], w.lin(wname), bias=w.vec(bname).unsqueeze(0))
+        ops.geglu_fwd(ff1, out=gg[lo:hi])
+        for a, e in ((0, lo), (hi, geo.T)):
+            if e > a:
+                ops.gemm(n[a:e], w.geglu_lin(wname), bias=w.geglu_vec(bname), geglu=True, out=gg[a:e])
+        return gg, ff1
+
     # ---- modules -----------------------------------------------------------------------------------
     def _resnet(self, p, x, x2, tb_all, geo, tape):
         """ResnetBlock3D.forward (resnet.py:183-213); x2 = skip tensor of the up-block concat or None"""
@@ -339,12 +363,7 @@ class UNet3DEngine:
                       residual=h1)
         # GEGLU feed-forward
         n3, ls3 = ops.layernorm_fwd(h2, w.vec(b + "norm3.weight"), w.vec(b + "norm3.bias"), save_stats=tape is not None)
-        if tape is None:   # no backward: h * gelu(gate) is formed in the GEMM epilogue, the [T, 8C] tensor never exists
-            ff1 = None
-            gg = ops.gemm(n3, w.geglu_lin(b + "ff.net.0.proj.weight"), bias=w.geglu_vec(b + "ff.net.0.proj.bias"), geglu=True)
-        else:
-            ff1 = ops.gemm(n3, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
-            gg = ops.geglu_fwd(ff1)
+        gg, bff1 = self._ff_geglu(n3, b, geo, tape)
         del n3
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
@@ -355,7 +374,7 @@ class UNet3DEngine:
         g1, cut = self._bslice(geo, tape.grad_batch)
         bx, bst, bh0, bh1, bh2 = cut(x), cut(st), cut(h0), cut(h1), cut(h2)
         bls1, bls2, bls3, bqkv, ba1, blse1 = cut(ls1), cut(ls2), cut(ls3), cut(qkv), cut(a1), cut(lse1)
-        bq2, bkv, ba2, blse2, bff1 = cut(q2), cut(kv), cut(a2), cut(lse2), cut(ff1)
+        bq2, bkv, ba2, blse2 = cut(q2), cut(kv), cut(a2), cut(lse2)   # (bff1: already the differentiated rows)
         fr1, hw1, T1 = g1.frames, g1.hw, g1.T
 
         def bwd():
@@ -418,12 +437,7 @@ class UNet3DEngine:
             h = hnext
         h2 = h
         n, lsf = ops.layernorm_fwd(h2, w.vec(b + "ff_norm.weight"), w.vec(b + "ff_norm.bias"), save_stats=tape is not None)
-        if tape is None:
-            ff1 = None
-            gg = ops.gemm(n, w.geglu_lin(b + "ff.net.0.proj.weight"), bias=w.geglu_vec(b + "ff.net.0.proj.bias"), geglu=True)
-        else:
-            ff1 = ops.gemm(n, w.lin(b + "ff.net.0.proj.weight"), bias=w.vec(b + "ff.net.0.proj.bias").unsqueeze(0))
-            gg = ops.geglu_fwd(ff1)
+        gg, bff1 = self._ff_geglu(n, b, geo, tape)
         del n
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
@@ -432,7 +446,7 @@ class UNet3DEngine:
             return out
 
         g1, cut = self._bslice(geo, tape.grad_batch)
-        bx, bst, bh2, blsf, bff1 = cut(x), cut(st), cut(h2), cut(lsf), cut(ff1)
+        bx, bst, bh2, blsf = cut(x), cut(st), cut(h2), cut(lsf)
         bsaved = [(cut(hin), cut(ls), cut(qkv), aname, ap) for (hin, ls, qkv, aname, ap) in saved]
         fr1, hw1, T1 = g1.frames, g1.hw, g1.T
 
