@@ -576,7 +576,9 @@ __global__ __launch_bounds__(256, (DT == 3 && QT == 2) ? 4 : 2) void attn_fwd_ri
                 // is stored as; this tile's scores move by the difference on the VALU, the accumulators (output rows and, in the
                 // ones row, the denominators) by 2^-difference
                 mx = rows_max(mx);
-                float mnew = (float)(half_t)(mfix[t] + mx);
+                // (saturating conversion: beyond +-65504 log2 units - where the reference's own fp16 scores are inf - the offset
+                // stops following instead of turning into inf)
+                float mnew = (float)to_half(mfix[t] + mx);
                 if (kt != 0) mnew = fmaxf(mnew, mfix[t]);
                 const float delta = mnew - mfix[t];
 #pragma unroll
