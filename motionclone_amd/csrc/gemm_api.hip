@@ -70,6 +70,10 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
             long b1 = (long)((M + 255) / 256) * (N / 320), b4 = (long)((M + 127) / 128) * (N / 320);
             if (b1 >= fill_of(224, share)) big_cfg = 1;
             else if (b4 >= fill_of(192, share)) big_cfg = 4;
+            // A/B only (MC_GEMM_ONEWAVE128=1): a launch of about one wave of 256-row tiles as two rounds of 128-row tiles, so the
+            // CUs fall out of lockstep between the k-loop and the epilogue's memory phase
+            static const int onewave128 = getenv("MC_GEMM_ONEWAVE128") ? atoi(getenv("MC_GEMM_ONEWAVE128")) : 0;
+            if (onewave128 && big_cfg == 1 && mode == DENSE && b1 <= 320) big_cfg = 4;
         }
     }
     if (big_cfg == 1 && automatic && !no_g5) {
