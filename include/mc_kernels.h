@@ -71,6 +71,9 @@ int mc_gemm_debug(int bits);
  * 2 / 20 = gemm2 128x128 / 64x64 tiles, 31..35 = gemm3 geometry 1..5, 4 = gemm4, 51 / 54 = gemm5 with 256- / 128-row tiles;
  * + 100 for a split-K call (bench.py names its roofline rows with it). */
 int mc_gemm_last_kernel(void);
+/* same for the spatial attention entries: 0 = register-staged kernels, 1 = LDS-DMA ring kernels (mc_attn_bwd_f16: bit 0 dQ, bit 1
+ * dK/dV) - profiling / tests only (attention.hip) */
+int mc_attn_last_kernel(void);
 int mc_tattn_debug_buffer(void* device_buffer); /* tools only: intermediates of mc_tattn_bwd_f16 (F <= 16, d = 40), units*64*24 floats */
 int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
 

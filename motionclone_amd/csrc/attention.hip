@@ -1356,6 +1356,10 @@ static void a_launch_fwd_ring(const AParams& P, half_t* o, int ldo, float* lse, 
     MC_LAUNCH((attn_fwd_ring_kernel<DT, QT, PADROW>), grid, dim3(256), smem, s, P, o, ldo, lse);
 }
 
+// which structure the calling thread's last spatial-attention entry ran (profiling / tests only): 0 register-staged kernels,
+// 1 LDS-DMA ring kernels; for mc_attn_bwd_f16 bit 0 = dQ kernel, bit 1 = dK/dV kernel
+static thread_local int g_attn_last = 0;
+
 // MC_ATTN_RING: 0 = never the LDS-DMA ring kernel, 2 = at every size it supports (tests), default = long sequences
 static int attn_ring_env() {
 #ifdef MC_EMU
@@ -1376,6 +1380,7 @@ static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipSt
         // V^T carries the denominators)
         // (any number of keys: the 77-key cross-attention gains 28 % as well - it is a stream over Q and O)
         if (!P.causal && P.d == (DT == 3 ? 40 : 80) && (ring == 2 || (ring && P.Nq >= 1024))) {
+            g_attn_last = 1;
             if constexpr (DT == 3) {
                 // MC_ATTN_QT=2: 32 rows per wave, 122 registers, four workgroups per CU - A/B only: 3-9 % SLOWER than 64 rows per wave
                 // at two workgroups per CU (profiles/r03_attn_qt_ab.jsonl): twice the LDS fragment reads and DMA issue per score
@@ -1448,6 +1453,7 @@ static void a_launch_dq(const AParams& P, const half_t* o, int ldo, const half_t
             allow_big_smem(attn_bwd_dq_ring_kernel<DT, QT>, smem);
             dim3 grid = attn_grid(P, (P.Nq + 64 * QT - 1) / (64 * QT));
             MC_LAUNCH((attn_bwd_dq_ring_kernel<DT, QT>), grid, dim3(256), smem, s, P, o, ldo, dO, lddo, lse, Dbuf, dq, lddq);
+            g_attn_last |= 1;
             return;
         }
     }
@@ -1469,6 +1475,7 @@ static void a_launch_dkdv(const AParams& P, const half_t* dO, int lddo, const fl
             allow_big_smem(attn_bwd_dkdv_ring_kernel<DT, KT>, smem);
             dim3 grid = attn_grid(P, (P.Nk + 64 * KT - 1) / (64 * KT));
             MC_LAUNCH((attn_bwd_dkdv_ring_kernel<DT, KT>), grid, dim3(256), smem, s, P, dO, lddo, lse, Dbuf, dk, lddk, dv, lddv);
+            g_attn_last |= 2;
             return;
         }
     }
@@ -1521,11 +1528,14 @@ extern "C" int mc_attn_fwd_f16(const void* q, const void* k, const void* v, int 
     if (!a_check(P) || ldo % 4) return MC_ERR_SHAPE;
     int dt = (d + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
+    g_attn_last = 0;
 #define CALL(DT_) a_launch_fwd<DT_>(P, (half_t*)o, ldo, lse, s)
     MC_A_DISPATCH(CALL)
 #undef CALL
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
+
+extern "C" int mc_attn_last_kernel(void) { return g_attn_last; }
 
 // causal self-attention forward (CLIP text encoder): same contract, key j masked for query i when j > i
 extern "C" int mc_attn_fwd_causal_f16(const void* q, const void* k, const void* v, int ldq, int ldk, int ldv, void* o,
@@ -1551,6 +1561,7 @@ extern "C" int mc_attn_bwd_f16(const void* q, const void* k, const void* v, int 
     if ((dk || dv) && (!dk || !dv || kv_bdiv != 1 || lddk % 4 || lddv % 4)) return MC_ERR_SHAPE;
     int dt = (d + 15) / 16;
     hipStream_t s = (hipStream_t)stream;
+    g_attn_last = 0;
 #define CALL(DT_)                                                                                             \
     a_launch_dq<DT_>(P, (const half_t*)o, ldo, (const half_t*)dO, lddo, lse, Dbuf, (half_t*)dq, lddq, s);     \
     if (dk) a_launch_dkdv<DT_>(P, (const half_t*)dO, lddo, lse, Dbuf, (half_t*)dk, lddk, (half_t*)dv, lddv, s)

@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as Fn
 
-from motionclone_amd import ops
+from motionclone_amd import lib, ops
 
 
 def big(dev):
@@ -461,6 +461,7 @@ def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share, d):
     k, v = kv[:, :C], kv[:, C:]
     monkeypatch.setenv("MC_ATTN_RING", "2")
     o, lse = ops.attn_fwd(q, k, v, Nq, Nk, heads, d, nb, kv_bdiv=share)
+    assert lib.load().mc_attn_last_kernel() == 1, "the ring kernel was not selected"
     Q = _heads(q, nb, Nq, heads, d)
     K = _heads(k, nb // share, Nk, heads, d).repeat_interleave(share, 0)
     V = _heads(v, nb // share, Nk, heads, d).repeat_interleave(share, 0)
@@ -501,10 +502,12 @@ def test_attention_backward_ring_kernels(backend, monkeypatch, Nq, Nk, share, d)
     gq, gk, gv = torch.autograd.grad(ref, (Q, K0, V0), _heads(do, nb, Nq, heads, d))
     if share == 1:
         dq, dk, dv = ops.attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nb)
+        assert lib.load().mc_attn_last_kernel() == 3, "the ring backward kernels were not selected"
         close(_heads(dk, nb, Nk, heads, d), gk, 1e-2, 2e-2, "ring attn dk")
         close(_heads(dv, nb, Nk, heads, d), gv, 1e-2, 2e-2, "ring attn dv")
     else:
         dq, _, _ = ops.attn_bwd(q, k, v, o, do, lse, Nq, Nk, heads, d, nb, kv_bdiv=share, need_dkv=False)
+        assert lib.load().mc_attn_last_kernel() == 1
     close(_heads(dq, nb, Nq, heads, d), gq, 1e-2, 2e-2, "ring attn dq")
     if not big(dev):   # and against the register-staged kernels
         monkeypatch.setenv("MC_ATTN_RING", "0")
