@@ -74,6 +74,8 @@ int mc_gemm_last_kernel(void);
 /* same for the spatial attention entries: 0 = register-staged kernels, 1 = LDS-DMA ring kernels (mc_attn_bwd_f16: bit 0 dQ, bit 1
  * dK/dV) - profiling / tests only (attention.hip) */
 int mc_attn_last_kernel(void);
+/* temporal attention: 1 = the calling thread's last mc_tattn_fwd_f16 / mc_tattn_bwd_f16 ran the 16-byte-load kernel (temporal.hip) */
+int mc_tattn_last_kernel(void);
 int mc_tattn_debug_buffer(void* device_buffer); /* tools only: intermediates of mc_tattn_bwd_f16 (F <= 16, d = 40), units*64*24 floats */
 int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
 

@@ -637,18 +637,21 @@ __global__ void reduce_sum_kernel(const float* in, long n, float scale, float* o
     if (threadIdx.x == 0) out[0] = (red[0] + red[1] + red[2] + red[3]) * scale;
 }
 
+static thread_local int g_tattn_last = 0;   // 1: the calling thread's last temporal-attention entry ran a 16-byte-load kernel
 static float* g_tattn_debug_buf = nullptr;   // mc_tattn_debug_buffer: intermediates of the F <= 16, d = 40 backward (tools only)
 
 template <int NT, int DT>
 static void t_launch_fwd(const TParams& P, half_t* o, int ldo, int mode, half_t* tv, uint8_t* ti,
                          const uint8_t* ri, const float* rv, float* ul, hipStream_t s) {
     long units = (long)P.B * P.HW * P.heads;
+    g_tattn_last = 0;
     if constexpr (DT == 3 || DT == 5 || DT == 10) {
         // attention output, rows readable 16 bytes at a time (MC_TATTN_VEC=0: the 8-byte kernel, A/B)
         static const int vec_env = getenv("MC_TATTN_VEC") ? atoi(getenv("MC_TATTN_VEC")) : 1;
         const bool aligned = ((uintptr_t)P.q | (uintptr_t)P.k | (uintptr_t)P.v) % 16 == 0;
         if (mode == 0 && vec_env && P.d % 8 == 0 && P.ld % 8 == 0 && aligned) {
             MC_LAUNCH((tattn_fwd_vec_kernel<NT, (DT + 1) / 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, o, ldo);
+            g_tattn_last = 1;
             return;
         }
     }
@@ -659,6 +662,7 @@ template <int NT, int DT>
 static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* dq, half_t* dk, half_t* dv,
                          int ldg, const uint8_t* ri, const float* rv, float coef, hipStream_t s) {
     long units = (long)P.B * P.HW * P.heads;
+    g_tattn_last = 0;
     if constexpr (NT == 1 && DT == 3) {
         if (g_tattn_debug_buf) {
             MC_LAUNCH((tattn_bwd_kernel<NT, DT, 1>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
@@ -676,6 +680,7 @@ static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* d
             allow_big_smem(tattn_bwd_kernel<NT, DT, 0, true>, smem);
             MC_LAUNCH((tattn_bwd_kernel<NT, DT, 0, true>), dim3((unsigned)((units + 3) / 4)), dim3(256), smem, s, P, dO, lddo,
                       dq, dk, dv, ldg, ri, rv, coef, (float*)nullptr);
+            g_tattn_last = 1;
             return;
         }
     }
@@ -717,6 +722,8 @@ static TParams t_params(const void* q, const void* k, const void* v, int ld, int
     P.ld = ld; P.B = B; P.F = F; P.HW = HW; P.heads = heads; P.d = d; P.scale = scale;
     return P;
 }
+
+extern "C" int mc_tattn_last_kernel(void) { return g_tattn_last; }
 
 extern "C" int mc_tattn_fwd_f16(const void* q, const void* k, const void* v, int ld, void* o, int ldo, int B,
                                 int F, int HW, int heads, int d, float scale, void* stream) {

@@ -30,6 +30,7 @@ SIGNATURES = {
     "mc_gemm_debug": [I],
     "mc_gemm_last_kernel": [],
     "mc_attn_last_kernel": [],
+    "mc_tattn_last_kernel": [],
     "mc_gemm_debug_buffer": [P],
     "mc_tattn_debug_buffer": [P],
     "mc_softmax_rows_f16": [P, I, I, I, P],

@@ -92,7 +92,7 @@ def _cost(name, a):
         frames, H, W, C = a[4], a[5], a[6], a[7]
         return ("sumpool2", 0.0, 2.0 * frames * H * W * C * 5, (frames * H * W, C))
     if name.startswith("mc_workspace_bytes_") or name in ("mc_version", "mc_gemm_splitk_plan", "mc_gn_nchunk", "mc_gemm_debug",
-                                                          "mc_gemm_last_kernel", "mc_attn_last_kernel", "mc_gemm_debug_buffer",
+                                                          "mc_gemm_last_kernel", "mc_attn_last_kernel", "mc_tattn_last_kernel", "mc_gemm_debug_buffer",
                                                           "mc_tattn_debug_buffer"):
         return None
     return (name[3:].replace("_f16", "").replace("_f32", ""), 0.0, 0.0, ())   # small elementwise / layout kernels
@@ -127,6 +127,8 @@ class LaunchProbe:
                 fam = _gemm_name(lib.load().mc_gemm_last_kernel(), shape[0])
             elif fam.startswith("attn_") and lib.load().mc_attn_last_kernel():
                 fam = fam.replace("attn_fwd", "attn_fwd_ring").replace("attn_bwd", "attn_bwd_ring")   # which structure ran
+            elif fam in ("tattn_fwd", "tattn_bwd") and lib.load().mc_tattn_last_kernel():
+                fam += "_vec"
             probe.records.append((fam, e0, e1, fl, nb, shape))
             return rc
         lib.call = call

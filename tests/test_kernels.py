@@ -561,6 +561,8 @@ def test_temporal_attention_and_guidance(backend, F_, d):
     qkv = rnd((B * F_ * HW, 3 * C), dev, 1, 0.8)
     q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
     o = ops.tattn_fwd(q, k, v, B, F_, HW, heads, d)
+    # head dims 40 / 80 / 160 with 16-byte readable rows take the vector-load kernel (temporal.hip tattn_fwd_vec_kernel)
+    assert lib.load().mc_tattn_last_kernel() == (1 if d in (40, 80, 160) else 0)
     Q, K, V = (t.requires_grad_() for t in _temporal_ref(qkv, B, F_, HW, heads, d))
     P = ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1)  # [B*HW, heads, F, F]
     ref = P @ V
