@@ -454,7 +454,8 @@ def test_attention_forward_ring_kernel(backend, monkeypatch, Nq, Nk, share, d):
     dev = backend
     heads, nb = 2, 2 * share
     if big(dev):
-        Nq, Nk, heads = Nq * 8 + 5, (Nk * 8 + 3 if Nk != 77 else 77 * 8), 8
+        # (>= 1024 query rows: the sizes that select the ring kernel by default; MC_ATTN_RING is read once per process there)
+        Nq, Nk, heads = Nq * (8 if Nq >= 128 else 16) + 5, (Nk * 8 + 3 if Nk != 77 else 77 * 8), 8
     C = heads * d
     q = rnd((nb * Nq, C), dev, 21, 0.7)
     kv = rnd((nb // share * Nk, 2 * C), dev, 22, 0.7)
@@ -484,7 +485,7 @@ def test_attention_backward_ring_kernels(backend, monkeypatch, Nq, Nk, share, d)
     dev = backend
     heads, nb = 2, 2 * share
     if big(dev):
-        Nq, Nk, heads = Nq * 8 + 4, (Nk * 8 + 4 if Nk != 77 else 77 * 8), 8
+        Nq, Nk, heads = Nq * (8 if Nq >= 128 else 16) + 4, (Nk * 8 + 4 if Nk != 77 else 77 * 8), 8
         if share == 1:
             Nk = Nq
     C = heads * d
