@@ -139,6 +139,7 @@ __device__ __forceinline__ void gn_block_stats(const float* partial, int frame, 
         float a = 0.f;
         int c = 0;
         for (; c + 8 <= nchunk; c += 8) {
+#pragma clang fp reassociate(off)   // fast-math would turn the eight ordered adds into a tree: different last bits than finalize
             float v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) v[u] = q[(size_t)(c + u) * 64];
