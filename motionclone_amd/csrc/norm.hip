@@ -111,6 +111,7 @@ __global__ void gn_finalize_kernel(const float* partial, float* stats, int frame
     int frame = i / 32, g = i % 32;
     float a = 0.f, b = 0.f;
     for (int c = 0; c < nchunk; ++c) {
+#pragma clang fp reassociate(off)   // chunk order 0 .. nchunk-1 exactly (fast-math would split the reduction): gn_block_stats adds alike
         const float* q = partial + ((size_t)(frame * nchunk + c) * 32 + g) * 2;
         a += q[0];
         b += q[1];
@@ -127,7 +128,7 @@ __global__ void gn_finalize_kernel(const float* partial, float* stats, int frame
 }
 
 // Round 3: the finalize pass INSIDE its consumers.  The 64 group totals of this block's frame are summed from the per-chunk
-// partials by 64 threads (chunk order 0 .. nchunk-1, the order gn_finalize_kernel uses: bit-identical statistics) and turned into
+// partials by 64 threads (chunk order 0 .. nchunk-1, the order gn_finalize_kernel uses; both loops are kept from being reassociated) and turned into
 // (mean, rstd) [mode 0] or (s1 / n, s2 / n) [mode 1] in LDS; chunk 0 of every frame also writes them to `stats_out` (the backward
 // and the C ABI's stats tensor).  One launch less per GroupNorm (3.5 k launches per video).
 __device__ __forceinline__ void gn_block_stats(const float* partial, int frame, int nchunk, float n, float eps, int mode,

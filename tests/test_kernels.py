@@ -325,8 +325,11 @@ def test_groupnorm_fwd_bwd(backend, C1, C2, silu):
     close(_from_cl(y, NF, H, W), ref, 1e-2, 5e-3, "gn fwd")
     # the two-launch form the engine uses (statistics finalised in the apply pass's prologue): the same output and statistics
     y2, stats2 = ops.gn_fwd(xa, xb, gamma, beta, silu, NF, H * W, 1e-5)
-    assert torch.equal(y2, y), "mc_groupnorm_fwd_f16 differs from stats + apply"
-    assert torch.equal(stats2, stats), "mc_groupnorm_fwd_f16 leaves different statistics"
+    # (the same expressions compiled in two kernels under fast-math: the statistics may differ by an fp32 rounding, the output
+    # then by one fp16 step on a few elements)
+    close(stats2, stats, 1e-5, 1e-5, "mc_groupnorm_fwd_f16 statistics vs stats + apply")
+    close(y2, y, 2e-3, 2e-3, "mc_groupnorm_fwd_f16 output vs stats + apply")
+    assert (y2 != y).float().mean().item() < 0.02, "mc_groupnorm_fwd_f16 differs from stats + apply on more than 2 % of the elements"
     dz = rnd((NF, C, H, W), dev, 4)
     (dref,) = torch.autograd.grad(ref, xr, dz.float())
     dx = ops.gn_bwd(xa, xb, _to_cl(dz), stats, gamma, beta, silu, NF, H * W)
