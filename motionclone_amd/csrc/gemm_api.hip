@@ -81,7 +81,10 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         g_last_kernel = 51;
         if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
     }
-    if (big_cfg == 4 && automatic && !no_g5) {   // 128-row tiles with 8 waves instead of gemm3's 4-wave 128x320 geometry
+    // A/B only (MC_GEMM5_NO128=1): the 128-row launches back on gemm3's 4-wave 128x320 geometry, TWO workgroups per CU (one
+    // tile's epilogue under the other's k-loop) - slower when a launch is repeated (43.4 vs 37.7 us), not yet compared inside the step loop
+    static const int no_g5_128 = getenv("MC_GEMM5_NO128") ? atoi(getenv("MC_GEMM5_NO128")) : 0;
+    if (big_cfg == 4 && automatic && !no_g5 && !no_g5_128) {   // 128-row tiles with 8 waves instead of gemm3's 4-wave 128x320 geometry
         int rc5 = gemm5_dispatch(p, mode, 4, rowsA, s);
         g_last_kernel = 54;
         if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
