@@ -56,6 +56,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
     static const int g5_var = getenv("MC_GEMM5_VAR") ? atoi(getenv("MC_GEMM5_VAR")) : 0;   // A/B only
     const bool automatic = !big_cfg && !tile && !deep;   // an explicit cfg = 1 still means gemm3 (tests, A/B tools)
+    bool onewave_g3 = false;
     if (!big_cfg && !tile && !deep) {
         // measured on MI355X (profiles/r02_gemm4_microbench.md): the streaming kernel wins on the K = 320 Linear layers once
         // the problem has >= 256 row blocks of work; the 256x320 / 128x320 tiles win wherever they still fill the 256 CUs;
@@ -70,10 +71,14 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
             long b1 = (long)((M + 255) / 256) * (N / 320), b4 = (long)((M + 127) / 128) * (N / 320);
             if (b1 >= fill_of(224, share)) big_cfg = 1;
             else if (b4 >= fill_of(192, share)) big_cfg = 4;
-            // A/B only (MC_GEMM_ONEWAVE128=1): a launch of about one wave of 256-row tiles as two rounds of 128-row tiles, so the
-            // CUs fall out of lockstep between the k-loop and the epilogue's memory phase
+            // A/B only (MC_GEMM_ONEWAVE128=1 | 2): a launch of about one wave of 256-row tiles as 128-row tiles - 1: two rounds of
+            // gemm5 tiles (measured: 33.0 vs 33.8 videos/min), 2: gemm3's two workgroups per CU (not measured yet) - so that the CUs
+            // fall out of lockstep between the k-loop and the epilogue's memory phase
             static const int onewave128 = getenv("MC_GEMM_ONEWAVE128") ? atoi(getenv("MC_GEMM_ONEWAVE128")) : 0;
-            if (onewave128 && big_cfg == 1 && mode == DENSE && b1 <= 320) big_cfg = 4;
+            if (onewave128 && big_cfg == 1 && mode == DENSE && b1 <= 320) {
+                big_cfg = 4;
+                onewave_g3 = onewave128 == 2;   // 2: on gemm3's geometry (two 4-wave workgroups per CU, free to fall out of step)
+            }
         }
     }
     if (big_cfg == 1 && automatic && !no_g5) {
@@ -84,7 +89,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     // A/B only (MC_GEMM5_NO128=1): the 128-row launches back on gemm3's 4-wave 128x320 geometry, TWO workgroups per CU (one
     // tile's epilogue under the other's k-loop) - slower when a launch is repeated (43.4 vs 37.7 us), not yet compared inside the step loop
     static const int no_g5_128 = getenv("MC_GEMM5_NO128") ? atoi(getenv("MC_GEMM5_NO128")) : 0;
-    if (big_cfg == 4 && automatic && !no_g5 && !no_g5_128) {   // 128-row tiles with 8 waves instead of gemm3's 4-wave 128x320 geometry
+    if (big_cfg == 4 && automatic && !no_g5 && !no_g5_128 && !onewave_g3) {   // 128-row tiles with 8 waves instead of gemm3's 4-wave 128x320 geometry
         int rc5 = gemm5_dispatch(p, mode, 4, rowsA, s);
         g_last_kernel = 54;
         if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
