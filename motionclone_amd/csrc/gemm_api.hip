@@ -72,7 +72,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
             if (b1 >= fill_of(224, share)) big_cfg = 1;
             else if (b4 >= fill_of(192, share)) big_cfg = 4;
             // A/B only (MC_GEMM_ONEWAVE128=1 | 2): a launch of about one wave of 256-row tiles as 128-row tiles - 1: two rounds of
-            // gemm5 tiles (measured: 33.0 vs 33.8 videos/min), 2: gemm3's two workgroups per CU (not measured yet) - so that the CUs
+            // gemm5 tiles (measured: 33.0 vs 33.8 videos/min), 2: gemm3's two workgroups per CU (33.9 vs 35.0) - so that the CUs
             // fall out of lockstep between the k-loop and the epilogue's memory phase
             static const int onewave128 = getenv("MC_GEMM_ONEWAVE128") ? atoi(getenv("MC_GEMM_ONEWAVE128")) : 0;
             if (onewave128 && big_cfg == 1 && mode == DENSE && b1 <= 320) {
