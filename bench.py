@@ -214,6 +214,66 @@ def reference_gpu_baseline(dev, size=512, sched=(30, 18, 0.4)):
                                   "config-2 shape, schedule %s" % (torch.__version__, torch.cuda.get_device_name(0), list(sched)))
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: replace this process by `torch.distributed.run` with N ranks on this
+    node (one per GPU, rendezvous on 127.0.0.1 and a free port) running the same command line."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execv(sys.executable, cmd)
+
+
+def compact_line(res, detail_path, limit=4000):
+    """The ONE line the driver parses: the contract keys, the dominant kernel's roofline row and the CPU baseline, nothing
+    long.  Everything else (`roofline_by_kernel`, traffic per shape, VAE, eager loop, baselines) goes to `detail_path`."""
+    keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "sec_per_guided_step", "sec_per_plain_step", "sec_per_denoise_step",
+            "e2e_tflops_per_gpu", "e2e_frac_of_mfma_peak"]
+    line = {k: res[k] for k in keep if k in res}
+    r = res.get("roofline")
+    if r:
+        line["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
+                                                  "traffic_vs_algorithmic", "avg_launch_us", "launches",
+                                                  "share_of_probe_video")}
+    c = res.get("cpu_baseline")
+    if c:
+        line["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "cpu_model", "kind", "sample", "error")
+                                if c.get(k) is not None}
+    g = res.get("reference_gpu_baseline")
+    if g and "videos_per_min" in g:
+        line["stock_pytorch_gpu_videos_per_min"] = g["videos_per_min"]
+    if res.get("eager"):
+        line["eager_one_video_at_a_time_videos_per_min"] = res["eager"]["videos_per_min"]
+        line["identical_to_eager_path"] = res["eager"]["identical_to_graph_path"]
+    if res.get("hbm_footprint"):
+        line["peak_reserved_gib"] = res["hbm_footprint"]["peak_reserved_gib"]
+    line["detail"] = detail_path
+    out = json.dumps(line)
+    if len(out) > limit:      # never let a long string cost the record: drop the prose first
+        line.get("cpu_baseline", {}).pop("sample", None)
+        out = json.dumps(line)
+    assert len(out) <= limit, len(out)
+    return out
+
+
+def write_detail(res):
+    """full record -> profiles/r04_bench_detail.json (and gpurun_out/, which is what travels back from a GPU box)"""
+    rel = os.path.join("profiles", "r04_bench_detail.json")
+    for d in ("profiles", "gpurun_out"):
+        try:
+            os.makedirs(os.path.join(ROOT, d), exist_ok=True)
+            with open(os.path.join(ROOT, d, "r04_bench_detail.json"), "w") as f:
+                json.dump(res, f, indent=1)
+        except OSError:
+            pass
+    return rel
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +289,7 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--gemm-lanes", type=int, default=0, help="value handed to ops.set_gemm_share (0 = the number of videos in flight)")
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
+    ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r04_bench_detail.json")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     ap.add_argument("--inflight", type=int, default=3, help="independent videos processed concurrently per GPU (own HIP stream, "
                     "own sampler / graphs each).  At config 2: 2 in flight +8-10 %% videos/min over one (kernel tails and the "
@@ -238,10 +299,14 @@ def main():
                     "a single video for the last round when it can be avoided (4 -> 2 + 2, 5 -> 3 + 2, 7 -> 3 + 2 + 2)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        spawn_ranks(args.gpus)     # plain `python bench.py --gpus N`: become the N-rank launcher (does not return)
     rank = int(os.environ.get("RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
-    assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node %d, "
+                         "or without a launcher: bench.py starts its own ranks)" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
@@ -332,6 +397,10 @@ def main():
     warm_videos = max(NF, args.warmup)     # every lane's first pass captures its graphs / fills its allocator pool: never timed
     run_videos(warm_videos)
     torch.cuda.synchronize()
+    # what the warm-up's eager passes left cached in the ordinary pool is of no use to the replays (they live in the lanes'
+    # graph pools): hand it back, and count the footprint of the timed region on its own
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats(dev)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -343,6 +412,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    timed_reserved = torch.cuda.max_memory_reserved(dev) / 2 ** 30
+    timed_allocated = torch.cuda.max_memory_allocated(dev) / 2 ** 30
     assert torch.isfinite(out.float()).all(), "non-finite latents"
     if dist is not None:
         tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -420,10 +491,10 @@ def main():
         if roof_all:
             dom = max(roof_all, key=lambda n: roof_all[n]["share_of_probe_video"])   # dominant by time
             roof = dict(roof_all[dom], kernel=dom)
-        hbm = dict(peak_allocated_gib=torch.cuda.max_memory_allocated(dev) / 2 ** 30,
-                   peak_reserved_gib=torch.cuda.max_memory_reserved(dev) / 2 ** 30, videos_in_flight=NF,
-                   note="torch caching allocator, whole process (weights 2.4 GiB fp16 + packed copies, %d lanes of activations, "
-                        "their hipGraph pools, the eager probe sampler)" % NF)
+        hbm = dict(peak_allocated_gib=timed_allocated, peak_reserved_gib=timed_reserved, videos_in_flight=NF,
+                   whole_process_peak_reserved_gib=torch.cuda.max_memory_reserved(dev) / 2 ** 30,
+                   note="torch caching allocator during the TIMED region (weights 2.4 GiB fp16 + packed copies, %d lanes: "
+                        "static buffers + one hipGraph pool each); whole_process adds the eager probe video run afterwards" % NF)
         res = {
             "metric": "videos/min (%df x %dx%d SD1.5+AnimateDiff-v3 arch, %d-step DDIM, %d guided, MotionClone guidance)"
                       % (args.frames, args.size, args.size, N_STEPS, G_STEPS),
@@ -451,7 +522,7 @@ def main():
                              "`bound` is the roof it is closer to (dense fp16 MFMA 2.5 PF vs HBM 8 TB/s, algorithmic flop / bytes); "
                              "`traffic` = PMC HBM bytes per launch on the shapes listed in roofline_traffic_by_shape (profiles/), null "
                              "where not collected; per-kernel durations of the TIMED regime (graphs, videos in flight): rocprofv3 "
-                             "trace in profiles/r03_kernel_stats.md",
+                             "trace in profiles/r04_kernel_stats.md",
             "roofline_by_kernel": roof_all,
             "roofline_coverage_of_probe_video": probe.covered(probe_elapsed),
             "roofline_traffic_by_shape": traffic_rows,
@@ -477,7 +548,9 @@ def main():
                 res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:
             res["cpu_baseline"] = None
-        print(json.dumps(res))
+        detail = write_detail(res) if not args.no_detail else None
+        sys.stdout.flush()
+        print(compact_line(res, detail), flush=True)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -64,9 +64,6 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
 
-/* PROFILING ONLY: timing experiments that drop parts of the GEMM kernels (1 = no global stores, 2 = no MFMA loop,
- * 4 = no epilogue, 8 = no operand staging); outputs are garbage while set.  0 restores normal operation. */
-int mc_gemm_debug(int bits);
 /* PROFILING ONLY: the kernel structure used by the calling thread's last mc_gemm_f16 / mc_gemm_splitk_f16 call:
  * 2 / 20 = gemm2 128x128 / 64x64 tiles, 31..35 = gemm3 geometry 1..5, 4 = gemm4, 51 / 54 = gemm5 with 256- / 128-row tiles;
  * + 100 for a split-K call (bench.py names its roofline rows with it). */
@@ -76,8 +73,15 @@ int mc_gemm_last_kernel(void);
 int mc_attn_last_kernel(void);
 /* temporal attention: 1 = the calling thread's last mc_tattn_fwd_f16 / mc_tattn_bwd_f16 ran the 16-byte-load kernel (temporal.hip) */
 int mc_tattn_last_kernel(void);
-int mc_tattn_debug_buffer(void* device_buffer); /* tools only: intermediates of mc_tattn_bwd_f16 (F <= 16, d = 40), units*64*24 floats */
+#ifdef MC_TOOLS
+/* TOOLS BUILD ONLY (-DMC_TOOLS: tools/_build/libmotionclone_hip_tools.so and the host simulator of tests/): process-wide
+ * debug state and environment A/B switches.  The product library exports none of these and reads no environment variable. */
+/* timing experiments that drop parts of the GEMM kernels (1 = no global stores, 2 = no MFMA loop, 4 = no epilogue,
+ * 8 = no operand staging); outputs are garbage while set.  0 restores normal operation. */
+int mc_gemm_debug(int bits);
+int mc_tattn_debug_buffer(void* device_buffer); /* intermediates of mc_tattn_bwd_f16 (F <= 16, d = 40), units*64*24 floats */
 int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
+#endif
 
 /* Split-K variant for small-M / deep-K problems (the 8x8 and 16x16-level 3x3 convs of unet_blocks.py:Downsample3D /
  * ResnetBlock3D at reference motionclone/models/resnet.py:110-209): K is cut into `splits` ranges computed by

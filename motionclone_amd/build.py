@@ -49,16 +49,24 @@ def _deps():
     return [os.path.join(CSRC, s) for s in SOURCES] + sorted(glob.glob(os.path.join(CSRC, "*.hpp")))
 
 
-def build_hip(force=False, verbose=False):
-    """Compile every HIP source for gfx950 and link csrc/libmotionclone_hip.so."""
+TOOLS_LIB = os.path.join(REPO, "tools", "_build", "libmotionclone_hip_tools.so")
+
+
+def build_hip(force=False, verbose=False, tools=False):
+    """Compile every HIP source for gfx950 and link csrc/libmotionclone_hip.so.
+
+    tools=True: the same sources with -DMC_TOOLS -> tools/_build/libmotionclone_hip_tools.so, the library the A/B scripts
+    under tools/ load through MC_HIP_LIB: it reads the MC_* environment switches and exports mc_gemm_debug* /
+    mc_tattn_debug_buffer.  The product library (tools=False) has no environment read and no mutable global."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = HIP_FLAGS
+    flags = HIP_FLAGS + (["-DMC_TOOLS"] if tools else [])
+    out_lib = TOOLS_LIB if tools else HIP_LIB
     stamp = _stamp(_deps(), " ".join(flags))
-    stamp_file = HIP_LIB + ".stamp"
-    if not force and os.path.exists(HIP_LIB) and os.path.exists(stamp_file):
+    stamp_file = out_lib + ".stamp"
+    if not force and os.path.exists(out_lib) and os.path.exists(stamp_file):
         if open(stamp_file).read() == stamp:
-            return HIP_LIB
-    objdir = os.path.join(CSRC, "build")
+            return out_lib
+    objdir = os.path.join(os.path.dirname(TOOLS_LIB), "obj") if tools else os.path.join(CSRC, "build")
     os.makedirs(objdir, exist_ok=True)
 
     def one(src):
@@ -70,17 +78,17 @@ def build_hip(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
         objs = list(ex.map(one, SOURCES))
-    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", HIP_LIB] + objs)
+    _run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out_lib] + objs)
     with open(stamp_file, "w") as f:
         f.write(stamp)
-    return HIP_LIB
+    return out_lib
 
 
 def build_slp_control(force=False):
     """TEST ONLY: the negative control of the determinism stress test (temporal.hip with SLP vectorisation)."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     src = os.path.join(CSRC, "temporal.hip")
-    flags = [f for f in HIP_FLAGS if f != "-fno-slp-vectorize"]
+    flags = [f for f in HIP_FLAGS if f != "-fno-slp-vectorize"] + ["-DMC_TOOLS"]
     stamp = _stamp([src, os.path.join(CSRC, "mc_common.hpp")], " ".join(flags))
     stamp_file = SLP_CONTROL_LIB + ".stamp"
     if not force and os.path.exists(SLP_CONTROL_LIB) and os.path.exists(stamp_file) and open(stamp_file).read() == stamp:
@@ -124,5 +132,7 @@ def build_emu(force=False):
 if __name__ == "__main__":
     if "--emu" in sys.argv:
         print(build_emu(force="--force" in sys.argv))
+    elif "--tools" in sys.argv:
+        print(build_hip(force="--force" in sys.argv, verbose=True, tools=True))
     else:
         print(build_hip(force="--force" in sys.argv, verbose=True))

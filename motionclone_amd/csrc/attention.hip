@@ -1362,18 +1362,13 @@ static thread_local int g_attn_last = 0;
 
 // MC_ATTN_RING: 0 = never the LDS-DMA ring kernel, 2 = at every size it supports (tests), default = long sequences
 static int attn_ring_env() {
-#ifdef MC_EMU
-    return getenv("MC_ATTN_RING") ? atoi(getenv("MC_ATTN_RING")) : 1;   // re-read per call: the tests flip it
-#else
-    static const int v = getenv("MC_ATTN_RING") ? atoi(getenv("MC_ATTN_RING")) : 1;
-    return v;
-#endif
+    return MC_ENV_INT("MC_ATTN_RING", 1);   // simulator / tools builds: re-read per call (the tests flip it); product: constant 1
 }
 
 template <int DT>
 static void a_launch_fwd(const AParams& P, half_t* o, int ldo, float* lse, hipStream_t s) {
-    static const int qt_env = getenv("MC_ATTN_QT") ? atoi(getenv("MC_ATTN_QT")) : 0;
-    static const int pf_env = getenv("MC_ATTN_PF") ? atoi(getenv("MC_ATTN_PF")) : -1;
+    static const int qt_env = MC_ENV_INT("MC_ATTN_QT", 0);
+    static const int pf_env = MC_ENV_INT("MC_ATTN_PF", -1);
     if constexpr (DT == 3 || DT == 5) {
         const int ring = attn_ring_env();
         // d = 40 / 80 exactly: the ring kernels need the padding k-slots of the 16-wide remainder step (and say which row of
@@ -1432,7 +1427,7 @@ static void a_launch_dkdv_cfg(const AParams& P, const half_t* dO, int lddo, cons
 // at d = 40 (level-0 backward of a 512^2 video 2.86 -> 2.55 ms, tools/attn_ablate.py; MC_ATTN_BQT overrides);
 // head dim 160 keeps one tile (the accumulators alone would need > 256 registers)
 static int bwd_tiles(int rows, int dt) {
-    static const int env = getenv("MC_ATTN_BQT") ? atoi(getenv("MC_ATTN_BQT")) : 0;
+    static const int env = MC_ENV_INT("MC_ATTN_BQT", 0);
     if (dt > 5) return 1;
     if (env) return env;
     if (dt == 3 && rows >= 2048) return 4;
@@ -1511,11 +1506,7 @@ static AParams a_params(const void* q, const void* k, const void* v, int ldq, in
     P.nbatch = nbatch; P.kv_bdiv = kv_bdiv; P.scale = scale; P.causal = 0;
     // one (batch, head) per XCD at a time pays when several row blocks share a K / V worth caching and there are units for all
     // 8 XCDs; MC_ATTN_XCD=0 restores the plain grid (A/B), 2 takes the mapping at every size (tests)
-#ifdef MC_EMU
-    const int xcd_env = getenv("MC_ATTN_XCD") ? atoi(getenv("MC_ATTN_XCD")) : 1;   // re-read per call: the tests flip it
-#else
-    static const int xcd_env = getenv("MC_ATTN_XCD") ? atoi(getenv("MC_ATTN_XCD")) : 1;
-#endif
+    const int xcd_env = MC_ENV_INT("MC_ATTN_XCD", 1);   // simulator / tools builds: re-read per call (the tests flip it)
     P.xcd_map = xcd_env == 2 || (xcd_env && heads * nbatch >= 8 && Nq >= 512 && Nk >= 512);
     return P;
 }

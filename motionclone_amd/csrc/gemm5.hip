@@ -468,7 +468,7 @@ static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, 
     // super-tile of the XCD-local tile order: sn divides the N-tiles, sm x sn ~ 32 workgroups, least operand rows per tile
     const int rows_per_xcd = (tM + 7) / 8;
     int sm = 1, sn = 1;
-    static const int no_swz = getenv("MC_GEMM5_NO_SUPERTILE") ? atoi(getenv("MC_GEMM5_NO_SUPERTILE")) : 0;   // A/B only
+    static const int no_swz = MC_ENV_INT("MC_GEMM5_NO_SUPERTILE", 0);   // A/B only
     // a weight matrix that fits the XCD's 4 MiB L2 beside the streaming activations is reused ACROSS M-tiles by the old order
     // (measured: qkv of level 1, 2.4 MB of weights, 100 -> 118 us with super-tiles); larger ones are re-streamed per M-tile
     const bool w_resident = (size_t)p.N * p.K * 2 <= (size_t)3 << 20;

@@ -17,7 +17,8 @@ int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStre
 
 using namespace mc;
 
-// PROFILING ONLY (tools/): timing experiments that drop parts of a GEMM kernel (GemmParams::dbg); results are garbage.
+#ifdef MC_TOOLS
+// TOOLS BUILD ONLY: timing experiments that drop parts of a GEMM kernel (GemmParams::dbg); results are garbage.
 static int g_gemm_debug = 0;
 static float* g_gemm_debug_buf = nullptr;
 extern "C" int mc_gemm_debug(int bits) {
@@ -28,6 +29,7 @@ extern "C" int mc_gemm_debug_buffer(void* buf) {   // device buffer for in-kerne
     g_gemm_debug_buf = (float*)buf;
     return 0;
 }
+#endif
 
 // `share` (mc_gemm_f16 flags bits 20-21, mc_gemm_splitk_plan mode bits 8-9): the caller keeps 2^share independent launch
 // sequences in flight on separate streams (sampler.sample_interleaved), so one launch only has to fill 1 / 2^share of the
@@ -53,15 +55,15 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         g_last_kernel = big_cfg == 15 ? 54 : 51;
         return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);
     }
-    static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
-    static const int g5_var = getenv("MC_GEMM5_VAR") ? atoi(getenv("MC_GEMM5_VAR")) : 0;   // A/B only
+    static const int no_g5 = MC_ENV_INT("MC_NO_GEMM5", 0);     // A/B, tools build only
+    static const int g5_var = MC_ENV_INT("MC_GEMM5_VAR", 0);   // A/B, tools build only
     const bool automatic = !big_cfg && !tile && !deep;   // an explicit cfg = 1 still means gemm3 (tests, A/B tools)
     bool onewave_g3 = false;
     if (!big_cfg && !tile && !deep) {
         // measured on MI355X (profiles/r02_gemm4_microbench.md): the streaming kernel wins on the K = 320 Linear layers once
         // the problem has >= 256 row blocks of work; the 256x320 / 128x320 tiles win wherever they still fill the 256 CUs;
         // smaller problems stay on the 128x128 / 64x64 tiles
-        static const int no_g4 = getenv("MC_NO_GEMM4") ? atoi(getenv("MC_NO_GEMM4")) : 0;   // diagnosis only
+        static const int no_g4 = MC_ENV_INT("MC_NO_GEMM4", 0);   // diagnosis, tools build only
         if (!no_g4 && mode == DENSE && p.K == 320 && !p.A2 && (M >= 98304 || (M >= 32768 && N >= 640))) {
             int rc4 = gemm4_dispatch(p, 0, s);
             g_last_kernel = 4;
@@ -74,7 +76,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
             // A/B only (MC_GEMM_ONEWAVE128=1 | 2): a launch of about one wave of 256-row tiles as 128-row tiles - 1: two rounds of
             // gemm5 tiles (measured: 33.0 vs 33.8 videos/min), 2: gemm3's two workgroups per CU (33.9 vs 35.0) - so that the CUs
             // fall out of lockstep between the k-loop and the epilogue's memory phase
-            static const int onewave128 = getenv("MC_GEMM_ONEWAVE128") ? atoi(getenv("MC_GEMM_ONEWAVE128")) : 0;
+            static const int onewave128 = MC_ENV_INT("MC_GEMM_ONEWAVE128", 0);
             if (onewave128 && big_cfg == 1 && mode == DENSE && b1 <= 320) {
                 big_cfg = 4;
                 onewave_g3 = onewave128 == 2;   // 2: on gemm3's geometry (two 4-wave workgroups per CU, free to fall out of step)
@@ -88,7 +90,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     }
     // A/B only (MC_GEMM5_NO128=1): the 128-row launches back on gemm3's 4-wave 128x320 geometry, TWO workgroups per CU (one
     // tile's epilogue under the other's k-loop) - slower when a launch is repeated (43.4 vs 37.7 us), not yet compared inside the step loop
-    static const int no_g5_128 = getenv("MC_GEMM5_NO128") ? atoi(getenv("MC_GEMM5_NO128")) : 0;
+    static const int no_g5_128 = MC_ENV_INT("MC_GEMM5_NO128", 0);
     if (big_cfg == 4 && automatic && !no_g5 && !no_g5_128 && !onewave_g3) {   // 128-row tiles with 8 waves instead of gemm3's 4-wave 128x320 geometry
         int rc5 = gemm5_dispatch(p, mode, 4, rowsA, s);
         g_last_kernel = 54;
@@ -138,16 +140,21 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
     p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = lda2; p.ldc = ldc; p.ldr = ldr;
     p.c1 = c1; p.ctot = ctot; p.Hs = Hs; p.Ws = Ws; p.Ho = Ho; p.Wo = Wo;
     p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi;
-    static const int dbg_env = getenv("MC_GEMM_DEBUG") ? atoi(getenv("MC_GEMM_DEBUG")) : 0;
+#ifdef MC_TOOLS
+    static const int dbg_env = MC_ENV_INT("MC_GEMM_DEBUG", 0);
     p.dbg = dbg_env | g_gemm_debug;
     p.ws = (p.dbg & 16) ? g_gemm_debug_buf : nullptr;
+#else
+    p.dbg = 0;
+    p.ws = nullptr;
+#endif
     p.splits = 1;
     p.s2_pad = (flags & 0x800) ? 0 : 1;
     hipStream_t s = (hipStream_t)stream;
 
     // 2 GiB descriptor limit: cut the problem into row ranges (whole frames for the conv modes).  With a per-batch bias
     // every range either holds whole batch entries or lies inside one, so its bias rows are a contiguous slice.
-    static const size_t lim_env = getenv("MC_GEMM_OPERAND_LIMIT") ? (size_t)atol(getenv("MC_GEMM_OPERAND_LIMIT")) : 0;   // tests
+    static const size_t lim_env = (size_t)MC_ENV_INT("MC_GEMM_OPERAND_LIMIT", 0);   // tests (simulator build) only
     const size_t lim = lim_env ? lim_env : (size_t)0x7FFFFFF0u;
     const size_t out_cols = epi ? (size_t)N / 2 : (size_t)N;
     const size_t per_out_row = 2 * (size_t)std::max(std::max(ldc, ldr), (int)out_cols);
@@ -297,7 +304,7 @@ extern "C" int mc_gemm_splitk_f16(const void* A, const void* A2, const void* W, 
     hipStream_t s = (hipStream_t)stream;
     size_t rowsA = mode == DENSE ? (size_t)M : (size_t)(M / (Ho * Wo)) * Hs * Ws;
     // gemm5 (ring kernel, 256- or 128-row tiles): partial sums in accumulator-native slabs + its own reduce / epilogue pass
-    static const int no_g5 = getenv("MC_NO_GEMM5") ? atoi(getenv("MC_NO_GEMM5")) : 0;   // A/B only
+    static const int no_g5 = MC_ENV_INT("MC_NO_GEMM5", 0);   // A/B, tools build only
     if (!no_g5 && splits > 1 && (cfg == 1 || cfg == 4) && !(flags & 0x1000000)) {
         GemmParams q = p;
         q.R = (const half_t*)R; q.bias = bias;

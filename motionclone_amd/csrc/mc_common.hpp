@@ -18,6 +18,24 @@
 #include <type_traits>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
+
+// The TEST / TOOLS builds (-DMC_TOOLS: tests/hipemu and tools/_build/libmotionclone_hip_tools.so, never loaded by the
+// package) read A/B switches from the environment and export the profiling hooks (mc_gemm_debug* / mc_tattn_debug_buffer).
+// The PRODUCT library has neither: no environment read, no mutable global - MC_ENV_INT folds to its default and the
+// variable name does not even reach the binary (tests/test_abi.py checks `nm -D` and the string table).
+#if defined(MC_EMU) && !defined(MC_TOOLS)
+#define MC_TOOLS 1
+#endif
+#ifdef MC_TOOLS
+static inline int mc_env_int(const char* name, int dflt) {
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+#define MC_ENV_INT(name, dflt) mc_env_int(name, dflt)
+#else
+#define MC_ENV_INT(name, dflt) (dflt)
+#endif
 
 namespace mc {
 

@@ -147,7 +147,10 @@ __device__ __forceinline__ void gn_block_stats(const float* partial, int frame, 
 #pragma unroll
             for (int u = 0; u < 8; ++u) a += v[u];
         }
-        for (; c < nchunk; ++c) a += q[(size_t)c * 64];
+        for (; c < nchunk; ++c) {
+#pragma clang fp reassociate(off)   // the remainder chunks in order too (an unrolled remainder would be re-associated alike)
+            a += q[(size_t)c * 64];
+        }
         lds[t] = a;
     }
     __syncthreads();
@@ -618,8 +621,10 @@ extern "C" int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int
 }
 
 // statistics + normalisation (+ SiLU) of one GroupNorm in TWO launches: per-chunk partial sums, then the apply pass, which
-// finalises the statistics in its prologue and writes them to `stats` (float[frames*32*2], for the backward).  Same results as
-// mc_groupnorm_stats_f16 followed by mc_groupnorm_apply_f16, bit for bit.  workspace: partial as for mc_groupnorm_stats_f16.
+// finalises the statistics in its prologue and writes them to `stats` (float[frames*32*2], for the backward).  Same sums in the
+// same order as mc_groupnorm_stats_f16 followed by mc_groupnorm_apply_f16; (mean, rstd) are the same expressions compiled in
+// two kernels under fast-math, so they may differ by an fp32 rounding and the output by one fp16 step on a few elements
+// (tests/test_kernels.py::test_groupnorm_fwd_bwd bounds both).  workspace: partial as for mc_groupnorm_stats_f16.
 extern "C" int mc_groupnorm_fwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
                                     float eps, float* partial, float* stats, const float* gamma, const float* beta,
                                     void* out, int ldo, int silu, void* stream) {
@@ -643,12 +648,11 @@ extern "C" int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int l
     GnSrc s;
     if (!make_src(&s, a, b, lda, ldb, c1, ctot, hw) || lddz % 8 || lddx % 8) return MC_ERR_SHAPE;
     int R, threads;
-    if (!gn_geometry(ctot, &R, &threads)) return MC_ERR_UNSUPPORTED;
+    if (!gn_geometry(ctot, &R, &threads) || threads < 64) return MC_ERR_UNSUPPORTED;   // checked BEFORE anything is launched
     int nchunk = mc_gn_nchunk(hw);
     size_t smem = (size_t)2 * R * ctot * sizeof(float);
     MC_LAUNCH(gn_bwd_partial_kernel, dim3(nchunk, frames), dim3(threads), smem, (hipStream_t)stream, s,
               (const half_t*)dz, lddz, stats, gamma, beta, silu, R, nchunk, partial);
-    if (threads < 64) return MC_ERR_UNSUPPORTED;
     MC_LAUNCH(gn_bwd_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, (const half_t*)dz,
               lddz, stats, bstats, gamma, beta, silu, (half_t*)dx, lddx, R, nchunk, accumulate, (const float*)partial,
               (float)hw * s.cpg);

@@ -638,7 +638,9 @@ __global__ void reduce_sum_kernel(const float* in, long n, float scale, float* o
 }
 
 static thread_local int g_tattn_last = 0;   // 1: the calling thread's last temporal-attention entry ran a 16-byte-load kernel
-static float* g_tattn_debug_buf = nullptr;   // mc_tattn_debug_buffer: intermediates of the F <= 16, d = 40 backward (tools only)
+#ifdef MC_TOOLS
+static float* g_tattn_debug_buf = nullptr;   // mc_tattn_debug_buffer: intermediates of the F <= 16, d = 40 backward (tools build only)
+#endif
 
 template <int NT, int DT>
 static void t_launch_fwd(const TParams& P, half_t* o, int ldo, int mode, half_t* tv, uint8_t* ti,
@@ -647,7 +649,7 @@ static void t_launch_fwd(const TParams& P, half_t* o, int ldo, int mode, half_t*
     g_tattn_last = 0;
     if constexpr (DT == 3 || DT == 5 || DT == 10) {
         // attention output, rows readable 16 bytes at a time (MC_TATTN_VEC=0: the 8-byte kernel, A/B)
-        static const int vec_env = getenv("MC_TATTN_VEC") ? atoi(getenv("MC_TATTN_VEC")) : 1;
+        static const int vec_env = MC_ENV_INT("MC_TATTN_VEC", 1);
         const bool aligned = ((uintptr_t)P.q | (uintptr_t)P.k | (uintptr_t)P.v) % 16 == 0;
         if (mode == 0 && vec_env && P.d % 8 == 0 && P.ld % 8 == 0 && aligned) {
             MC_LAUNCH((tattn_fwd_vec_kernel<NT, (DT + 1) / 2>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, o, ldo);
@@ -663,6 +665,7 @@ static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* d
                          int ldg, const uint8_t* ri, const float* rv, float coef, hipStream_t s) {
     long units = (long)P.B * P.HW * P.heads;
     g_tattn_last = 0;
+#ifdef MC_TOOLS
     if constexpr (NT == 1 && DT == 3) {
         if (g_tattn_debug_buf) {
             MC_LAUNCH((tattn_bwd_kernel<NT, DT, 1>), dim3((unsigned)((units + 3) / 4)), dim3(256), 0, s, P, dO, lddo,
@@ -670,8 +673,9 @@ static void t_launch_bwd(const TParams& P, const half_t* dO, int lddo, half_t* d
             return;
         }
     }
+#endif
     if constexpr (DT == 3 || DT == 5 || DT == 10) {
-        static const int vec_env = getenv("MC_TATTN_VEC") ? atoi(getenv("MC_TATTN_VEC")) : 1;
+        static const int vec_env = MC_ENV_INT("MC_TATTN_VEC", 1);
         const bool aligned = ((uintptr_t)P.q | (uintptr_t)P.k | (uintptr_t)P.v | (uintptr_t)dO) % 16 == 0;
         constexpr int NS = (DT + 1) / 2;
         constexpr size_t smem = (size_t)4 * 3 * 16 * NT * (64 * NS + 16);
@@ -800,10 +804,12 @@ extern "C" int mc_tattn_bwd_f16(const void* q, const void* k, const void* v, int
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
+#ifdef MC_TOOLS
 extern "C" int mc_tattn_debug_buffer(void* buf) {   // units * 64 * 24 floats, or null to switch the dump off
     g_tattn_debug_buf = (float*)buf;
     return 0;
 }
+#endif
 
 extern "C" int mc_reduce_sum_f32(const float* in, long n, float scale, float* out, void* stream) {
     if (n <= 0) return MC_ERR_SHAPE;

@@ -107,36 +107,73 @@ def broadcast_state(obj=None, src=0, device=None):
     return obj if rank == src else _unpack(skel, flat, offsets)
 
 
+class _Failed:
+    """cache entry of a checkpoint whose read failed: waiters re-raise instead of waiting for ever"""
+
+    def __init__(self, exc):
+        self.exc = exc
+
+
 class SharedCheckpoints:
     """`load(key, reader)`: the checkpoint file `key` is READ ONCE PER JOB - by rank 0 - and reaches the other ranks by
     `broadcast_state` (the one collective of the path); inside a process it is loaded once and shared by all
     launcher lanes.  Collectives are only ever issued by lane 0's thread (every rank's lane 0 walks the script in the same
-    order, so the broadcasts pair up); other lanes wait until lane 0 has published the key."""
+    order, so the broadcasts pair up); other lanes wait until lane 0 has published the key.
 
-    def __init__(self, device=None):
+    Failures are published too: if the reader raises (a wrong checkpoint path), the exception is cached, the waiting
+    lanes re-raise it, and - with several ranks - rank 0 sends an ok / error header BEFORE the payload so that the other
+    ranks raise instead of blocking in the broadcast.  `timeout` (seconds) bounds a lane's wait as a backstop."""
+
+    def __init__(self, device=None, timeout=1800.0):
         import threading
         self._cv = threading.Condition()
         self._cache = {}
         self._device = device
+        self._timeout = timeout
         self.reads = 0          # files actually read from disk by this process
         self.received = 0       # files received from rank 0
+
+    def _result(self, key):
+        ent = self._cache[key]
+        if isinstance(ent, _Failed):
+            raise ent.exc
+        return ent
 
     def load(self, key, reader, is_leader=True):
         with self._cv:
             if key in self._cache:
-                return self._cache[key]
+                return self._result(key)
             if not is_leader:
-                self._cv.wait_for(lambda: key in self._cache)
-                return self._cache[key]
+                if not self._cv.wait_for(lambda: key in self._cache, timeout=self._timeout):
+                    raise TimeoutError("checkpoint %r was not published by lane 0 within %.0f s" % (key, self._timeout))
+                return self._result(key)
         multi = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
-        if not multi or dist.get_rank() == 0:
-            obj = reader()
-            self.reads += 1
-            if multi:
-                broadcast_state(obj, 0, self._device)
-        else:
-            obj = broadcast_state(None, 0, self._device)
-            self.received += 1
+        try:
+            if not multi or dist.get_rank() == 0:
+                err = None
+                try:
+                    obj = reader()
+                    self.reads += 1
+                except BaseException as e:   # noqa: BLE001 - forwarded to the other ranks / lanes, then re-raised
+                    err = e
+                if multi:
+                    dist.broadcast_object_list([None if err is None else "%s: %s" % (type(err).__name__, err)], src=0)
+                if err is not None:
+                    raise err
+                if multi:
+                    broadcast_state(obj, 0, self._device)
+            else:
+                hdr = [None]
+                dist.broadcast_object_list(hdr, src=0)
+                if hdr[0] is not None:
+                    raise RuntimeError("rank 0 could not read checkpoint %r: %s" % (key, hdr[0]))
+                obj = broadcast_state(None, 0, self._device)
+                self.received += 1
+        except BaseException as e:   # noqa: BLE001
+            with self._cv:
+                self._cache[key] = _Failed(e)
+                self._cv.notify_all()
+            raise
         with self._cv:
             self._cache[key] = obj
             self._cv.notify_all()

@@ -184,18 +184,27 @@ def main(argv=None):
         if sharded and isinstance(path, (str, os.PathLike)) and os.path.abspath(path) == ex_abs and (not a or "r" in a[0]):
             vrank = rank + world * (mcl.lane_index() or 0)
             fb, fe = (warm_begin, warm_end) if n_lanes > 1 else (None, None)
+            if n_lanes > 1:      # the lane has built its models (their H2D copies synchronise): it is ready for the warm-up turns
+                with warm_turn:
+                    warm_state["ready"] += 1
+                    warm_turn.notify_all()
             return _ShardedLines(lines, vrank, vworld, burn if serial_rng else None, fb, fe)
         return real_open(path, *a, **k)
 
     # A lane's FIRST example runs alone: it captures the lane's step graphs, and ROCm 7.2 rejects synchronising calls of any
     # other host thread while a capture is open.  Turns are taken in lane order; when every lane has had its turn they all
     # continue concurrently (replays only; lanes.may_capture).
+    # No lane takes its turn before EVERY lane has opened the examples file, i.e. has finished load_state_dict / .to(cuda):
+    # those are synchronising calls too and would hit lane 0's open capture otherwise.  A lane that dies releases the others.
     warm_turn = threading.Condition()
-    warm_state = dict(turn=0)
+    warm_state = dict(turn=0, ready=0)
 
     def warm_begin():
         with warm_turn:
-            warm_turn.wait_for(lambda: warm_state["turn"] == (mcl.lane_index() or 0))
+            warm_turn.wait_for(lambda: errors or (warm_state["ready"] >= n_lanes
+                                                  and warm_state["turn"] == (mcl.lane_index() or 0)))
+            if errors:
+                raise RuntimeError("lane %d failed: %r" % errors[0])
 
     def warm_end():
         if on_gpu:
@@ -204,7 +213,7 @@ def main(argv=None):
         with warm_turn:
             warm_state["turn"] += 1
             warm_turn.notify_all()
-            warm_turn.wait_for(lambda: warm_state["turn"] >= n_lanes)
+            warm_turn.wait_for(lambda: errors or warm_state["turn"] >= n_lanes)
 
     def lane_argv(lane):
         out = sargv
@@ -250,6 +259,8 @@ def main(argv=None):
                 torch.cuda.current_stream().synchronize()
         except BaseException as e:   # noqa: BLE001 - reported by the main thread
             errors.append((lane, e))
+            with warm_turn:          # lanes waiting for their warm-up turn must not wait for a dead one
+                warm_turn.notify_all()
         finally:
             mcl.end()
 

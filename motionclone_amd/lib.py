@@ -27,12 +27,9 @@ SIGNATURES = {
     "mc_workspace_bytes_tattn_loss": [I, I, I],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
     "mc_gemm_splitk_plan": [I, I, I, I],
-    "mc_gemm_debug": [I],
     "mc_gemm_last_kernel": [],
     "mc_attn_last_kernel": [],
     "mc_tattn_last_kernel": [],
-    "mc_gemm_debug_buffer": [P],
-    "mc_tattn_debug_buffer": [P],
     "mc_softmax_rows_f16": [P, I, I, I, P],
     "mc_video_post_f32": [P, I, P, I, I, I, P],
     "mc_vae_sample_f16": [P, I, P, P, I, I, I, P],
@@ -68,6 +65,13 @@ SIGNATURES = {
     "mc_ddim_step_general_f16": [P, P, P, P, P, P, P, L, F, F, F, F, F, I, F, F, F, F, F, F, P],
 }
 
+# exported by the TOOLS build only (-DMC_TOOLS: tools/_build/libmotionclone_hip_tools.so, the host simulator): bound when present
+TOOLS_SIGNATURES = {
+    "mc_gemm_debug": [I],
+    "mc_gemm_debug_buffer": [P],
+    "mc_tattn_debug_buffer": [P],
+}
+
 ERRORS = {-1: "bad shape / stride / alignment", -2: "unsupported size", -3: "kernel launch failed"}
 
 _lib = None
@@ -84,6 +88,11 @@ def _bind(path):
         fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
         fn.argtypes = argtypes
         fn.restype = c_long if name.startswith("mc_workspace_bytes_") else c_int
+    for name, argtypes in TOOLS_SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is not None:
+            fn.argtypes = argtypes
+            fn.restype = c_int
     return lib
 
 

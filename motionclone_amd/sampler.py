@@ -62,6 +62,7 @@ class MotionCloneSampler:
         self.score_gs = float(score_guidance_scale)
         self._graphs = None      # step index -> (hipGraph, static input, static output); see enable_graphs()
         self._graph_pool = None
+        self._warm_kinds = set()  # {guided?} kinds of step that already ran once eagerly on this sampler (lazy init done)
 
     def _alphas(self, i):
         t = int(self.timesteps[i])
@@ -121,11 +122,17 @@ class MotionCloneSampler:
                 s_lat, s_text = latents.clone(), text.clone()
                 s_rep = {k: tuple(t.clone() for t in v) for k, v in rep_dev.items()} if guided else {}
                 s_ctrl = None if ctrl is None else dict(cond=ctrl["cond"].clone(), mask=ctrl["mask"].clone(), scale=ctrl.get("scale", 1.0))
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):          # eager pass first: lazy one-time work (function attributes, caches)
-                    first = self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
-                torch.cuda.current_stream().wait_stream(side)
+                # an eager pass before the FIRST capture of each kind of step (guided / plain): lazy one-time work (packed
+                # weights, function attributes, workspace caches) must not happen inside a capture.  Later captures of the same
+                # kind skip it - an eager guided step allocates its whole tape from the ordinary caching pool, and doing that
+                # for all 30 step indices of every lane is what held 63 GiB reserved for 18 GiB in use (round 3).
+                if guided not in self._warm_kinds:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
+                    torch.cuda.current_stream().wait_stream(side)
+                    self._warm_kinds.add(guided)
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: other host threads (launcher lanes) keep allocating / launching while this one captures
                 with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
@@ -133,7 +140,8 @@ class MotionCloneSampler:
                 if self._graph_pool is None:
                     self._graph_pool = graph.pool()
             self._graphs[key] = (graph, s_lat, s_text, s_rep, s_ctrl, s_out)
-            return first
+            graph.replay()       # the step's result comes from the graph it will be replayed from (bit-identical to eager)
+            return s_out
         graph, s_lat, s_text, s_rep, s_ctrl, s_out = ent
         s_lat.copy_(latents)
         if text.data_ptr() != s_text.data_ptr():
@@ -153,7 +161,10 @@ class MotionCloneSampler:
         """single_step_video (motionclone_functions.py:173-257): text = [uncond, cond] embeddings [2, n, dim];
         ctrl = dict(cond, mask, scale) enables the SparseCtrl pass of :176-197 (one B=2 encoder run per step);
         eta / generator / variance_noise = the `extra_step_kwargs` handed on to schedule_customized_step (:241,255):
-        eta > 0 adds eta * sigma_t * noise, drawn like randn_tensor unless given (never captured in a graph)"""
+        eta > 0 adds eta * sigma_t * noise, drawn like randn_tensor unless given (never captured in a graph).
+        ALIASING: with `enable_graphs()` a replayed step returns the graph's static output buffer - valid until the same
+        step index is replayed again (the next video on this sampler); callers that keep a result across videos clone it
+        (the drop-in `single_step_video` / `sample_video` do)."""
         if eta:
             if variance_noise is not None and generator is not None:
                 raise ValueError("Cannot pass both generator and variance_noise. Please make sure that either `generator` or"

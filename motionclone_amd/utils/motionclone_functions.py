@@ -49,13 +49,18 @@ def _sampler(pipe):
     c = pipe.input_config
     sch = pipe.scheduler
     # reading the scheduler's tables is a device -> host copy: done again only when the scheduler's tensors were replaced or
-    # written (customized_set_timesteps assigns a new tensor), not on every step
-    tkey = (id(sch.timesteps), getattr(sch.timesteps, "_version", 0), id(sch.alphas_cumprod),
-            getattr(sch.alphas_cumprod, "_version", 0))
-    if getattr(pipe, "_mc_sched_key", None) != tkey:
+    # written (customized_set_timesteps assigns a new tensor), not on every step.  The cache HOLDS the tensor objects and
+    # compares with `is` + `_version` (an id() alone can be reused by a new tensor once the old one is freed); tables that are
+    # not tensors (numpy arrays, lists: in-place edits leave no trace) are re-read every call - they are host data anyway.
+    cached = getattr(pipe, "_mc_sched_src", None)
+    fresh = (cached is None or cached[0] is not sch.timesteps or cached[2] is not sch.alphas_cumprod
+             or not isinstance(sch.timesteps, torch.Tensor) or not isinstance(sch.alphas_cumprod, torch.Tensor)
+             or cached[1] != sch.timesteps._version or cached[3] != sch.alphas_cumprod._version)
+    if fresh:
         pipe._mc_sched_tables = (tuple(int(t) for t in torch.as_tensor(sch.timesteps).cpu().tolist()),
                                  torch.as_tensor(sch.alphas_cumprod).detach().float().cpu())
-        pipe._mc_sched_key = tkey
+        pipe._mc_sched_src = (sch.timesteps, getattr(sch.timesteps, "_version", 0), sch.alphas_cumprod,
+                              getattr(sch.alphas_cumprod, "_version", 0))
     ts, acp = pipe._mc_sched_tables
     final = float(getattr(sch, "final_alpha_cumprod", 1.0))
     if len(ts) != int(c.inference_steps):
@@ -186,6 +191,10 @@ def single_step_video(self, noisy_latents, step_index, step_t, extra_step_kwargs
     kw = dict(extra_step_kwargs or {})      # prepare_extra_step_kwargs: eta / generator, handed to customized_step (:241,255)
     out = smp.step(noisy_latents.half(), step_index, self.text_embeddings.half(), self._mc_rep_dev, ctrl=ctrl,
                    eta=float(kw.get("eta", 0.0) or 0.0), generator=kw.get("generator") if kw.get("eta") else None)
+    # a replayed step returns the graph's STATIC output buffer (sampler._graphed_step), which the next replay of the same
+    # step index - the next video - overwrites; the reference API hands out fresh tensors, so the boundary copies (0.5 MiB)
+    if smp._graphs is not None:
+        out = out.clone()
     return out.detach()
 
 

@@ -58,3 +58,63 @@ def test_two_rank_replicas_gloo():
     assert ex0 == [0, 2, 4] and ex1 == [1, 3]  # round-robin sharding, every example exactly once
     assert t0 == t1 == 2.0                     # max over ranks
     assert p0 != p1                            # per-rank representation files
+
+
+def test_failed_checkpoint_read_reaches_the_waiting_lanes():
+    """a reader that raises (wrong path) must not leave the other lanes waiting: the failure is published and re-raised"""
+    import threading
+    import pytest
+    shared = mcd.SharedCheckpoints(timeout=20.0)
+    got = {}
+
+    def follower():
+        try:
+            shared.load("missing.ckpt", lambda: 1 / 0, is_leader=False)
+        except BaseException as e:   # noqa: BLE001
+            got["exc"] = e
+    th = threading.Thread(target=follower)
+    th.start()
+
+    def reader():
+        raise FileNotFoundError("missing.ckpt")
+    with pytest.raises(FileNotFoundError):
+        shared.load("missing.ckpt", reader, is_leader=True)
+    th.join(timeout=30)
+    assert not th.is_alive() and isinstance(got.get("exc"), FileNotFoundError)
+    with pytest.raises(FileNotFoundError):     # and stays failed for late comers
+        shared.load("missing.ckpt", reader, is_leader=False)
+    # a follower whose leader never shows up gives up instead of blocking for ever
+    with pytest.raises(TimeoutError):
+        mcd.SharedCheckpoints(timeout=0.2).load("never.ckpt", reader, is_leader=False)
+
+
+def _failing_worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    mcd.init("gloo")
+    shared = mcd.SharedCheckpoints()
+
+    def reader():
+        raise FileNotFoundError("no such checkpoint")
+    try:
+        shared.load("ckpt", reader)
+        out.put((rank, "no error"))
+    except Exception as e:   # noqa: BLE001
+        out.put((rank, "%s: %s" % (type(e).__name__, e)))
+    torch.distributed.destroy_process_group()
+
+
+def test_failed_checkpoint_read_on_rank0_raises_on_every_rank_gloo():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_failing_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0].startswith("FileNotFoundError") and "rank 0 could not read" in res[1] and "FileNotFoundError" in res[1]

@@ -1,6 +1,7 @@
 """Spatial attention at the shapes of config 2 (16f x 512^2, 8 heads; CFG doubles the frame batch) on cuda:0 -> JSON lines.
 Run once per setting of the library's switches (read once per process): `MC_ATTN_RING=0 MC_ATTN_TAG=old python
 tools/attn_bench.py [--fwd-only]`."""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702,F401  (tools build of the library: MC_* switches / debug hooks)
 import json
 import os
 import sys

@@ -1,5 +1,6 @@
 """What the per-tile fixed cost of the 256x320 GEMM is made of: MC_GEMM_DEBUG=1 (no output stores), 32 (streaming stores)
 against the shipped kernel, on the shapes where it weighs most (K = 640 / 1280 Linear layers, one wave of tiles)."""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702,F401  (tools build of the library: MC_* switches / debug hooks)
 import os, sys, torch
 sys.path.insert(0, ".")
 from motionclone_amd import ops

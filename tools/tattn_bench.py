@@ -1,5 +1,6 @@
 """Temporal attention forward / backward at the shapes of config 2 (CFG batch 2 x 16 frames) on cuda:0 -> JSON lines.
 Run once per setting of MC_TATTN_VEC (read once per process)."""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702,F401  (tools build of the library: MC_* switches / debug hooks)
 import json
 import os
 import sys

@@ -17,6 +17,7 @@ Variants (all from the SAME source, csrc/temporal.hip):
 A run = the F = 16, d = 40, 4096-pixel backward (config-2 level-0 shape of up_blocks.1's neighbour) quiet, then N times
 with 12 level-0 spatial-attention forwards in flight on a second stream; a run "differs" if any of dq / dk / dv differs
 bitwise from the quiet result; the number of differing (pixel, head) units is reported for the worst run."""
+import os as _os, sys as _sys; _sys.path.insert(0, _os.path.dirname(_os.path.abspath(__file__))); import _toolslib  # noqa: E401,E702,F401  (tools build of the library: MC_* switches / debug hooks)
 import argparse
 import ctypes
 import json
