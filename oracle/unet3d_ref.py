@@ -242,7 +242,42 @@ def resnet_block(sd, p, x, temb, cfg):
     return x + h
 
 
-MHA_MAX_SCORE_BYTES = 12 << 30   # no-grad attention is evaluated in batch chunks above this score-matrix size
+MHA_MAX_SCORE_BYTES = 12 << 30   # attention is evaluated in batch chunks above this score-matrix size
+
+
+class _ChunkedAttention(torch.autograd.Function):
+    """softmax(q k^T scale) v per (batch, head) slice, a few batch entries (= frames) at a time, WITH a backward that
+    recomputes the probabilities chunk by chunk instead of keeping them: the reference's `_attention` materialises
+    [B*heads, N, N] at once and autograd keeps it (attention.py:461-490) - 87 GB in fp32 per level-0 self-attention at
+    32 f x 96 x 96, two of them inside the differentiated half.  Every slice's arithmetic is what the unchunked path
+    computes (same matmuls, same softmax, torch's own softmax-backward formula); tests/test_oracle_pins.py holds the two
+    paths against each other, forward and gradients."""
+
+    @staticmethod
+    def forward(ctx, qh, kh, vh, scale, step):
+        ctx.save_for_backward(qh, kh, vh)
+        ctx.scale, ctx.step = scale, step
+        out = [torch.softmax(qh[i:i + step] @ kh[i:i + step].transpose(-1, -2) * scale, dim=-1) @ vh[i:i + step]
+               for i in range(0, qh.shape[0], step)]
+        return torch.cat(out, 0)
+
+    @staticmethod
+    def backward(ctx, go):
+        qh, kh, vh = ctx.saved_tensors
+        scale, step = ctx.scale, ctx.step
+        dq, dk, dv = torch.empty_like(qh), torch.empty_like(kh), torch.empty_like(vh)
+        for i in range(0, qh.shape[0], step):
+            q, k, v, g = qh[i:i + step], kh[i:i + step], vh[i:i + step], go[i:i + step]
+            p = torch.softmax(q @ k.transpose(-1, -2) * scale, dim=-1)
+            dv[i:i + step] = p.transpose(-1, -2) @ g
+            dp = g @ v.transpose(-1, -2)
+            ds = (dp - (dp * p).sum(-1, keepdim=True)) * p          # softmax backward (torch: _softmax_backward_data)
+            del dp, p
+            ds = ds * scale
+            dq[i:i + step] = ds @ k
+            dk[i:i + step] = ds.transpose(-1, -2) @ q
+            del ds
+        return dq, dk, dv, None, None
 
 
 def _mha(q, k, v, heads):
@@ -253,13 +288,10 @@ def _mha(q, k, v, heads):
     kh = k.reshape(Bq, -1, heads, d).transpose(1, 2)
     vh = v.reshape(Bq, -1, heads, d).transpose(1, 2)
     score_bytes = Bq * heads * Nq * kh.shape[2] * q.element_size()
-    if score_bytes > MHA_MAX_SCORE_BYTES and not torch.is_grad_enabled():
-        # same arithmetic per (batch, head) slice, evaluated a few batch elements at a time: the reference's
-        # `_attention` materialises [B*heads, N, N] at once (attention.py:461-490), which at 32 f x 96 x 96 is 87 GB in fp32
+    if score_bytes > MHA_MAX_SCORE_BYTES:
+        # same arithmetic per (batch, head) slice, evaluated a few batch elements at a time (and recomputed in the backward)
         step = max(1, int(Bq * MHA_MAX_SCORE_BYTES // score_bytes))
-        out = [torch.softmax(qh[i:i + step] @ kh[i:i + step].transpose(-1, -2) * d ** -0.5, dim=-1) @ vh[i:i + step]
-               for i in range(0, Bq, step)]
-        return torch.cat(out, 0).transpose(1, 2).reshape(Bq, Nq, C)
+        return _ChunkedAttention.apply(qh, kh, vh, d ** -0.5, step).transpose(1, 2).reshape(Bq, Nq, C)
     p = torch.softmax(qh @ kh.transpose(-1, -2) * d ** -0.5, dim=-1)
     return (p @ vh).transpose(1, 2).reshape(Bq, Nq, C)
 

@@ -19,9 +19,10 @@ HP = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_u
 # 1.8e-3, gradient 6.4e-3 .. 7.6e-3, loss 1e-4 .. 3.3e-4, tie gap <= 3e-4, flips <= 0.31 % of the rows) so that a 3x regression
 # fails; the counts move by a few rows from run to run of the ORACLE (its fp32 GEMMs pick different split-K orders per shape).
 TOL_FWD, TOL_GRAD, TOL_LOSS = 5e-3, 2e-2, 2e-3
-TIE_GAP = 1e-3                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
+TIE_GAP = 5e-4                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
+#                                                     (round 4: 1e-3 -> 5e-4; the worst gap ever measured is 3.4e-4)
 MAX_FLIP_FRACTION = 5e-3
-REPORT_FILE = "parity_r03.json"
+REPORT_FILE = "parity_r04.json"
 
 _REPORT = {}
 
@@ -167,9 +168,11 @@ def check_plain_step(eng, smp, sdo, cfg, lat, text, step_index, key, ctrl=None, 
     return nxt, ref_nxt
 
 
-def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=None, start_ref=None):
+def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=None, start_ref=None, ctrl=None, csdo=None):
     """Steps [first, last) of the loop (sample_video, motionclone_functions.py:164-166): engine and oracle each follow
-    their OWN trajectory from a common start (`start_ref`: fp32 latents at step `first`, default the initial noise)."""
+    their OWN trajectory from a common start (`start_ref`: fp32 latents at step `first`, default the initial noise).
+    ctrl / csdo: SparseCtrl condition and the ControlNet's oracle weights - the encoder runs every step on the current
+    timestep (motionclone_functions.py:176-197), on both sides."""
     ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
     hp = dict(HP, guidance_steps=smp.G)
     rep_dev = eng.prepare_representation(rep_ref)
@@ -177,13 +180,21 @@ def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=N
     xr = lat.float() if start_ref is None else start_ref.float()
     x = xr.half()
     drift = []
+    shape2 = (2,) + tuple(lat.shape[1:])
     for i in range(first, last):
-        x = smp.step(x, i, text, rep_dev)
+        x = smp.step(x, i, text, rep_dev, ctrl=ctrl)
         with oracle_mode(lat.device):
+            d = m = None
+            if ctrl is not None:
+                with torch.no_grad():
+                    d, m = U.controlnet_forward(csdo, cfg, shape2, int(ts[i]), text.float(), ctrl["cond"].float(),
+                                                ctrl["mask"].float(), ctrl.get("scale", 1.0))
             if i < smp.G:
-                xr, _ = G.guided_step(sdo, cfg, xr, i, ts, text.float(), rep_ref, hp)
+                xr, _ = G.guided_step(sdo, cfg, xr, i, ts, text.float(), rep_ref, hp,
+                                      res_u=([t[[0]] for t in d], m[[0]]) if d else None,
+                                      res_c=([t[[1]] for t in d], m[[1]]) if d else None)
             else:
-                xr, _ = G.plain_step_full(sdo, cfg, xr, i, ts, text.float(), hp["cfg_scale"])
+                xr, _ = G.plain_step_full(sdo, cfg, xr, i, ts, text.float(), hp["cfg_scale"], res=(d, m) if d else None)
         drift.append(rel(x, xr))
     report(key, loop_drift=[round(d, 6) for d in drift], loop_steps=[first, last], loop_schedule=[smp.N, smp.G])
     assert torch.isfinite(x.float()).all()

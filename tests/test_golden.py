@@ -56,11 +56,23 @@ def test_engine_reproduces_reference_golden(backend):
     eps = eng.forward(lat.expand(2, -1, -1, -1, -1), int(smp.timesteps[0]), text)
     assert close(ops.cl_to_latent(eps, 2, 4, 4, 8, 8), g["eps_b2"], 2e-2)
     rep = smp.extract(g["vid"].half().to(dev), g["noise"].half().to(dev), text[0:1])
-    flips = 0
+    # index work: the uint8 arg-max must EQUAL the reference's, except where the fp32 probabilities (recomputed by the oracle,
+    # which the test above pins to this same golden file) hold a tie at the 5e-4 level - measured: 0 of 192 rows differ
+    rec = {}
+    with torch.no_grad():
+        noisy = G.add_noise(G.alphas_cumprod(), 400, g["vid"], g["noise"])
+        U.unet_forward(sd, cfg, noisy.float(), 400, g["text"][[0]], only_motion_feature=True, record=rec)
+        prob = G.temp_attn_prob(rec, cfg["motion_heads"])
+    flips = total = 0
     for k, (v, i) in g["rep"].items():
         assert close(rep[k][0], v, 1e-2)
-        flips += (rep[k][1].cpu() != i).float().mean().item()
-    assert flips / len(g["rep"]) < 0.02       # arg-max flips only at fp16-level ties
+        mine = rep[k][1].cpu()
+        mism = mine != i
+        flips, total = flips + int(mism.sum()), total + mism.numel()
+        if mism.any():
+            gap = (prob[k].max(-1, keepdim=True).values - torch.gather(prob[k], -1, mine.long()))[mism]
+            assert float(gap.max()) <= 5e-4, "an arg-max flip that is not a tie: gap %g" % float(gap.max())
+    assert flips <= max(1, total // 100), (flips, total)
     rep_dev = eng.prepare_representation(g["rep"])
     aux = {}
     nxt = smp.step(lat, 0, text, rep_dev, aux=aux)

@@ -77,3 +77,23 @@ def test_unet_forward_and_steps_match_reference():
     l_ref = H.step(p_ref, N - 1, text, rep_ref)
     l, _ = G.plain_step_full(sd, cfg, p, N - 1, ts, text, HP["cfg_scale"])
     assert _close(l, l_ref), (l_ref - l).abs().max()
+
+
+def test_chunked_attention_of_the_oracle_equals_the_unchunked_path(monkeypatch):
+    """the frame-chunked attention with recompute-in-backward (what lets the fp32 oracle differentiate 32 f x 96 x 96) against
+    the plain `_attention` restatement that the test above pins to the reference: forward and q / k / v gradients"""
+    g = torch.Generator().manual_seed(3)
+    B, N, M, heads, d = 5, 24, 17, 2, 8
+    q0, k0, v0 = (torch.randn(B, n, heads * d, generator=g, dtype=torch.float64) for n in (N, M, M))
+    w = torch.randn(B, N, heads * d, generator=g, dtype=torch.float64)
+    res = []
+    for limit in (U.MHA_MAX_SCORE_BYTES, 2 * heads * N * M * 8):       # unchunked; chunks of 2 batch entries (last one ragged)
+        monkeypatch.setattr(U, "MHA_MAX_SCORE_BYTES", limit)
+        q, k, v = (t.clone().requires_grad_() for t in (q0, k0, v0))
+        out = U._mha(q, k, v, heads)
+        res.append((out.detach(),) + torch.autograd.grad((out * w).sum(), (q, k, v)))
+        with torch.no_grad():
+            assert torch.equal(U._mha(q0, k0, v0, heads), out.detach())
+    for a, b in zip(*res):
+        assert torch.allclose(a, b, rtol=1e-12, atol=1e-13), (a - b).abs().max()
+    assert torch.equal(res[0][0], res[1][0])     # the forward is the same arithmetic slice by slice
