@@ -145,6 +145,7 @@ class Tape:
         self.grads = {}
         self.keep = []
         self.grad_batch = grad_batch   # differentiate only this batch element of a B > 1 forward (None: all)
+        self.grad_scale = 1.0          # the gradients on this tape are carried at this multiple of their value
 
     def add(self, fn):
         self.fns.append(fn)
@@ -554,7 +555,7 @@ class UNet3DEngine:
                 nb = 1 if tape.grad_batch is not None else B
                 dxin = ops.gemm(dout, w.conv_dgrad("conv_in.weight", pad_cin=CIN_PAD), mode=CONV_S1,
                                 geom=(H, W, H, W), m_out=nb * F * H * W)
-                tape.latent_grad = ops.cl_to_latent(dxin, nb, CL, F, H, W, scale=1.0 / self.grad_scale, f32=True)
+                tape.latent_grad = ops.cl_to_latent(dxin, nb, CL, F, H, W, scale=1.0 / tape.grad_scale, f32=True)
             tape.add(bwd_in)
         skips = [(x, geo)]
         for i in range(4):
@@ -652,10 +653,17 @@ class UNet3DEngine:
         Returns (eps_c tokens, grad fp32 [1,4,F,H,W], loss or None[, eps_u tokens])."""
         batched = text_uncond is not None
         tape = Tape(grad_batch=1 if batched else None)
+        # The loss is a MEAN over the attention maps (F.mse_loss, :229), so the gradient per element shrinks with the size of
+        # the problem: 4e-5 at the latent for config 2, 6e-6 for config 5 (32 f x 96^2), where `grad_scale` = 1024 left the deep
+        # layers' fp16 gradient activations in the subnormal range (gradient 1.8e-2 from the fp32 oracle against 7e-3 at every
+        # smaller size, tests/test_fullsize_parity.py).  The scale therefore follows the map size in powers of two from the
+        # validated point (config 2: 32768 elements per hooked attention): exact to undo, same dynamic range at every size.
+        numel_max = max((idx.numel() for idx, _ in rep_dev.values()), default=1)
+        tape.grad_scale = self.grad_scale * float(2 ** max(0, round(math.log2(max(1.0, numel_max / 32768.0)))))
         seeds = {}
         for name, (idx, val) in rep_dev.items():
             numel = idx.numel()
-            seeds[name] = (idx, val, self.grad_scale * float(weight) * 2.0 / numel)
+            seeds[name] = (idx, val, tape.grad_scale * float(weight) * 2.0 / numel)
         record = {}
         if batched:
             eps2 = self.forward(latents.expand(2, -1, -1, -1, -1), t, torch.cat([text_uncond, text_cond], 0), tape=tape,

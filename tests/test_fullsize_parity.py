@@ -88,7 +88,7 @@ def test_full_loop_config2(world):
     smp = sampler(eng, 30, 18, 0.4)
     with PU.oracle_mode(dev):
         rep_ref = G.extract_representation(sdo, cfg, vid.float(), noise.float(), text[0:1].float())
-    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg2_full_loop", tol=8e-3)
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg2_full_loop", tol=5e-3)   # measured 6.0e-4 -> 1.5e-3
     torch.cuda.empty_cache()
 
 
@@ -116,7 +116,7 @@ def test_trajectory_config4_sparsectrl_across_the_switch(world):
                        mid_residual=mr)
         rep_ref = G.motion_representation(G.temp_attn_prob(rec, cfg["motion_heads"]))
     del dr, mr, rec
-    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg4_trajectory", tol=6e-3, first=8, last=16, ctrl=ctrl, csdo=csdo)
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg4_trajectory", tol=4e-3, first=8, last=16, ctrl=ctrl, csdo=csdo)
     torch.cuda.empty_cache()
 
 
