@@ -83,6 +83,20 @@ int mc_tattn_debug_buffer(void* device_buffer); /* intermediates of mc_tattn_bwd
 int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stamps of gemm4 land here */
 #endif
 
+/* Norm + Linear in ONE launch for the K = 320 level (round 4): C[M,N] = norm(A[M,320]) W[N,320]^T + bias, the normalisation
+ * applied to the rows of A in registers inside the streaming kernel (gemm4.hip) - the normalised tensor never exists in HBM.
+ *   kind 1: LayerNorm(gamma, beta, eps) over the 320 channels, + pe[(row / hw) % nframes_pe][:] when pe != NULL
+ *           (= mc_layernorm_fwd_f16 then mc_gemm_f16; reference attention.py:189,206,212 -> 355-364, motion_module.py:204-213);
+ *           stats: float[M][2] (mean, rstd) for mc_layernorm_bwd_f16, or NULL.  With pe: hw % 256 == 0.
+ *   kind 2: GroupNorm(32 groups, NO activation) over frames of hw tokens (= mc_groupnorm_fwd_f16(silu = 0) then mc_gemm_f16;
+ *           Transformer3DModel.norm + proj_in, attention.py:61-65,105-117; motion_module.py:112-113,145-151); hw % 256 == 0;
+ *           partial: workspace of mc_workspace_bytes_groupnorm(M / hw, hw); stats: float[(M / hw) * 32 * 2] out (for the backward).
+ * flags: 0x200 = fused GEGLU epilogue (as mc_gemm_f16).  Returns MC_ERR_UNSUPPORTED (-2) for shapes outside that kernel:
+ * the caller then issues the two-launch form. */
+int mc_norm_gemm_f16(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldc,
+                     int kind, const float* gamma, const float* beta, const float* pe, int hw, int nframes_pe, float eps,
+                     float* stats, float* partial, int flags, void* stream);
+
 /* Split-K variant for small-M / deep-K problems (the 8x8 and 16x16-level 3x3 convs of unet_blocks.py:Downsample3D /
  * ResnetBlock3D at reference motionclone/models/resnet.py:110-209): K is cut into `splits` ranges computed by
  * separate workgroups into the fp32 workspace ws[splits][M][N]; a reduce kernel applies bias / residual.

@@ -20,9 +20,20 @@
 // the per-chunk wait is vmcnt(0), placed after the chunk's MFMAs; the loads for later chunks (W two chunks ahead, residual
 // rows, bias) are issued after the chunk's stores, which therefore had a whole chunk of MFMAs to drain when waited for.
 #include "gemm_params.hpp"
+#include "gn_stats.hpp"
 
 namespace mc {
 
+// Round 4: a normalisation of the rows of A applied IN REGISTERS during the A phase, so that the normalised tensor is never
+// written to / read back from HBM (one launch and 4 T C bytes less per fused norm, at the level where the norms are HBM-bound):
+//   kind 1  LayerNorm over the K = 320 channels (+ the temporal position table): the lane pair (l, l + 32) holds one row,
+//           sum and sum of squares by v_dot2_f32_f16 (fp32) with one cross-lane add each, y = (x - mean) rstd gamma + beta
+//           [+ pe[frame]] in fp32, rounded to fp16 once - what ln_fwd5_kernel (norm.hip) computes, i.e. attention.py:189,206,212 /
+//           motion_module.py:204,210,237-246; (mean, rstd) optionally written for the backward;
+//   kind 2  GroupNorm WITHOUT activation (Transformer3DModel.norm / TemporalTransformer3DModel.norm, eps 1e-6): per frame an
+//           affine map x sc[k] + sh[k] (sc = rstd gamma, sh = beta - mean sc; the arithmetic of gn_apply_kernel); the
+//           statistics are finalised from the per-chunk partial sums in the prologue (gn_block_stats) and written for the
+//           backward by the first workgroup of every frame.  A workgroup's 256 rows lie in one frame (hw % 256 == 0).
 constexpr int G4_BM = 256;          // rows per workgroup
 constexpr int G4_BN = 32;           // output columns per chunk
 constexpr int G4_WRING = 0;         // LDS map (bytes): W ring 2 x KS/4 x 4 KiB
@@ -44,10 +55,10 @@ struct G4Lds {
 // in-place 8-byte accesses are 2-way (the minimum for 32 rows x 8 B), the 16-byte read-back is conflict-free.
 __device__ __forceinline__ int g4_stg_off(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
-template <int KS, bool GEGLU>
+template <int KS, bool GEGLU, int NORM>
 __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesW, uint32_t bytesC,
                                                         uint32_t bytesR, uint32_t bytesB, int tilesM, int nsplit,
-                                                        int chunks) {
+                                                        int chunks, G4Norm np) {
     using L = G4Lds<KS>;
     constexpr int KT = KS / 4;          // 64-wide k-tiles of a W chunk
     constexpr int NT = KS / 2;          // 32-wide landing tiles of A
@@ -136,6 +147,113 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
             raw_barrier();      // (waits lgkmcnt(0)): every wave has its fragments before the buffer is refilled
             if (kt + 2 < NT) issue_a(kt + 2, kt & 1);
         }
+    }
+    if (NORM != 0) {
+        // The landing ring is dead (every wave holds its fragments: last barrier of the A phase) and the staging image that
+        // shares its bytes is first written after the sweep's first barrier: room for the per-channel table
+        //   tab[0 .. K) scale / gamma   tab[K .. 2K) shift / beta (+ position row)   tab[3K .. 3K + 64) group stats
+        constexpr int KC = KS * 16;
+        float* tab = reinterpret_cast<float*>(sLand);
+        if (NORM == 2) {
+            const int frame = m0 / np.hw;
+            gn_block_stats(np.partial, frame, np.nchunk, np.gn_n, np.eps, 0, tab + 3 * KC, np.stats, ns == 0 && m0 % np.hw == 0);
+            for (int k = tid; k < KC; k += 256) {
+                const float* st = tab + 3 * KC + (k / (KC / 32)) * 2;
+                const float sc = st[1] * np.gamma[k];
+                tab[k] = sc;
+                tab[KC + k] = np.beta[k] - st[0] * sc;
+            }
+        } else {
+            const float* perow = np.pe ? np.pe + (size_t)((m0 / np.hw) % np.nframes_pe) * KC : nullptr;
+            for (int k = tid; k < KC; k += 256) {
+                tab[k] = np.gamma[k];
+                tab[KC + k] = np.beta[k] + (perow ? perow[k] : 0.f);     // the position row enters with the shift
+            }
+        }
+        __syncthreads();
+        // kind 1: (mean, rstd) of the lane pair's row from ONE pass of v_dot2_f32_f16 (sum: x . (1, 1); sum of squares: x . x;
+        // fp32 products and accumulation, var = E[x^2] - mean^2): 2 x 160 instructions per wave instead of the 1600 of a
+        // convert-and-accumulate two-pass form, whose fp32 copies the compiler kept (and spilled)
+        float nm[2] = {0.f, 0.f}, rs[2] = {1.f, 1.f};       // -mean * rstd, rstd
+        if (NORM == 1) {
+            half2_t ones;
+            ones[0] = ones[1] = (half_t)1.0f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float su[4] = {0.f, 0.f, 0.f, 0.f}, sqv[4] = {0.f, 0.f, 0.f, 0.f};   // four independent chains each
+#pragma unroll
+                for (int s = 0; s < KS; ++s)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        half2_t v;
+                        v[0] = a[j][s][2 * e];
+                        v[1] = a[j][s][2 * e + 1];
+                        su[e] = dot2acc(v, ones, su[e]);
+                        sqv[e] = dot2acc(v, v, sqv[e]);
+                    }
+                float sum = (su[0] + su[1]) + (su[2] + su[3]), sq = (sqv[0] + sqv[1]) + (sqv[2] + sqv[3]);
+                sum += shfl_xor(sum, 32);
+                sq += shfl_xor(sq, 32);
+                const float mean = sum / KC;
+                const float rstd = 1.0f / sqrtf(fmaxf(sq / KC - mean * mean, 0.f) + np.eps);
+                rs[j] = rstd;
+                nm[j] = -mean * rstd;
+                const int row = m0 + 64 * wave + 32 * j + l31;
+                if (np.stats && ns == 0 && lhi == 0 && row < p.M) {
+                    np.stats[(size_t)row * 2] = mean;
+                    np.stats[(size_t)row * 2 + 1] = rstd;
+                }
+            }
+        }
+        // slice by slice, both row blocks of a slice from ONE read of the table (with the row blocks outermost hipcc keeps the
+        // table of all 20 slices live across them - 320 floats - and spills 600-1300 registers).  Per element: one mixed-
+        // precision FMA (xhat = x rstd - mean rstd, the fp16 operand read directly), one FMA (gamma, beta + pe), half a packed
+        // convert; LayerNorm output cannot leave the fp16 range, so no saturation.  The affine map is one FMA + the convert.
+        const float* tl = tab + 8 * opaque(lhi);
+        f32x4 tg[2][2], tb[2][2];        // [parity of the slice][half]: the table of slice s + 1 is read while slice s is computed
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            tg[0][h] = *reinterpret_cast<const f32x4*>(tl + 4 * h);
+            tb[0][h] = *reinterpret_cast<const f32x4*>(tl + KC + 4 * h);
+        }
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            if (s + 1 < KS) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    tg[(s + 1) & 1][h] = *reinterpret_cast<const f32x4*>(tl + 16 * (s + 1) + 4 * h);
+                    tb[(s + 1) & 1][h] = *reinterpret_cast<const f32x4*>(tl + 16 * (s + 1) + KC + 4 * h);
+                }
+            }
+            float g[8], b[8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[4 * h + e] = tg[s & 1][h][e], b[4 * h + e] = tb[s & 1][h][e];
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                half8_t o;
+                if (NORM == 1) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = (half_t)(((float)a[j][s][e] * rs[j] + nm[j]) * g[e] + b[e]);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[e] = to_half((float)a[j][s][e] * g[e] + b[e]);
+                }
+#ifndef MC_EMU
+                {   // the converted fragment has to EXIST here (register-only work is not ordered by a memory clobber)
+                    u32x4 pin = __builtin_bit_cast(u32x4, o);
+                    asm volatile("" : "+v"(pin));
+                    o = __builtin_bit_cast(half8_t, pin);
+                }
+#endif
+                a[j][s] = o;
+            }
+#ifndef MC_EMU
+            __builtin_amdgcn_sched_barrier(0);     // one slice at a time (+ the next slice's table reads in flight)
+#endif
+        }
+        // (the table is dead: the barrier below separates its last read from the first staging write)
     }
     if (!GEGLU && p.R) issue_r(c_begin * G4_BN, lane);
     wait_vmcnt_le<0>();
@@ -286,9 +404,9 @@ __global__ __launch_bounds__(256, 2) void gemm4_kernel(GemmParams p, uint32_t by
     }
 }
 
-template <int KS, bool GEGLU>
+template <int KS, bool GEGLU, int NORM>
 static int launch4(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t bC, uint32_t bR, uint32_t bB, int nsplit,
-                   hipStream_t stream) {
+                   const G4Norm& np, hipStream_t stream) {
     const int tilesM = (p.M + G4_BM - 1) / G4_BM;
     const int nchunk_all = p.N / G4_BN;
     if (nsplit < 1) nsplit = 1;
@@ -298,20 +416,29 @@ static int launch4(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t bC, u
     chunks = (chunks + grp - 1) / grp * grp;
     nsplit = (nchunk_all + chunks - 1) / chunks;
     const size_t smem = G4Lds<KS>::total;
-    allow_big_smem(gemm4_kernel<KS, GEGLU>, smem);
+    allow_big_smem(gemm4_kernel<KS, GEGLU, NORM>, smem);
     dim3 grid((unsigned)(((tilesM + 7) / 8) * 8 * nsplit));
-    MC_LAUNCH((gemm4_kernel<KS, GEGLU>), grid, dim3(256), smem, stream, p, bA, bW, bC, bR, bB, tilesM, nsplit, chunks);
+    MC_LAUNCH((gemm4_kernel<KS, GEGLU, NORM>), grid, dim3(256), smem, stream, p, bA, bW, bC, bR, bB, tilesM, nsplit, chunks, np);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
 // DENSE, single A source, K = 320, N % 32 == 0, one bias row; optional residual, or the fused GEGLU epilogue (W rows
 // interleaved (h_j, gate_j), C gets N/2 columns).  nsplit = workgroups sharing one 256-row block of A (0 = automatic).
+// norm: null, or the normalisation applied to the rows of A in registers (G4Norm; no residual then).
 // Returns MC_ERR_UNSUPPORTED for anything else (the caller falls back to the tiled kernels).
-int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream) {
+int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4Norm* norm) {
     if (p.A2 || p.K != 320 || p.N % G4_BN || (p.ws && !(p.dbg & 16)) || p.splits != 1) return MC_ERR_UNSUPPORTED;
     if (p.epi && (p.R || p.alpha != 1.0f)) return MC_ERR_UNSUPPORTED;
     if (p.bias && p.rows_per_batch < p.M) return MC_ERR_UNSUPPORTED;
     if ((p.ldc & 7) || (p.R && (p.ldr & 7)) || (p.lda & 7)) return MC_ERR_UNSUPPORTED;
+    const int kind = norm ? norm->kind : 0;
+    if (kind) {
+        if (p.R || kind < 1 || kind > 2 || !norm->gamma || !norm->beta) return MC_ERR_UNSUPPORTED;
+        // the rows of a workgroup must lie in one frame wherever a per-frame quantity enters
+        if ((kind == 2 || norm->pe) && (norm->hw <= 0 || norm->hw % G4_BM || p.M % norm->hw)) return MC_ERR_UNSUPPORTED;
+        if (kind == 2 && (!norm->partial || !norm->stats || norm->nchunk <= 0)) return MC_ERR_UNSUPPORTED;
+        if (kind == 1 && norm->pe && norm->nframes_pe <= 0) return MC_ERR_UNSUPPORTED;
+    }
     const int ncol = p.epi ? p.N / 2 : p.N;
     const size_t lim = 0x7FFFFFF0u;
     const size_t bA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bW = (size_t)p.N * p.K * 2;
@@ -323,9 +450,12 @@ int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream) {
         nsplit = 1;
         while (tilesM * nsplit < 448 && (p.N / G4_BN) / (nsplit * 2) >= 5) nsplit *= 2;
     }
-    if (p.epi)
-        return launch4<20, true>(p, (uint32_t)bA, (uint32_t)bW, (uint32_t)bC, (uint32_t)bR, (uint32_t)bB, nsplit, stream);
-    return launch4<20, false>(p, (uint32_t)bA, (uint32_t)bW, (uint32_t)bC, (uint32_t)bR, (uint32_t)bB, nsplit, stream);
+    const G4Norm none{};
+    const G4Norm& np = norm ? *norm : none;
+#define G4_GO(GE, NO) launch4<20, GE, NO>(p, (uint32_t)bA, (uint32_t)bW, (uint32_t)bC, (uint32_t)bR, (uint32_t)bB, nsplit, np, stream)
+    if (p.epi) return kind == 0 ? G4_GO(true, 0) : (kind == 1 ? G4_GO(true, 1) : G4_GO(true, 2));
+    return kind == 0 ? G4_GO(false, 0) : (kind == 1 ? G4_GO(false, 1) : G4_GO(false, 2));
+#undef G4_GO
 }
 
 }  // namespace mc

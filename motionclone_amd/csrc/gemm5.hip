@@ -291,6 +291,10 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     const int kt_begin = (int)((long)split * nk_all / p.splits);
     const int nk = (int)((long)(split + 1) * nk_all / p.splits);
 
+    // (Round 4, measured and removed: touching the tile's residual rows with one 4-byte LDS-DMA load per 128-byte line before the
+    // first operand stage, so that the epilogue's lockstep read finds them in L2 / the Infinity Cache: every +R shape got
+    // SLOWER inside the step loop - 32768 x 640 x 640 52.7 -> 57.0 us, 131072 x 320 x 1280 162 -> 175 us, the convs +3 % -
+    // 34.6 vs 34.8 videos/min.  The rows compete with the operand stream for the same L2 while the k-loop runs.)
     // prologue: waves 0-3 put stages 0..2 in flight, waves 4-7 stages 0..3 (they issue stage j + 4 in the second half of j)
     const bool stagger = (VAR & 1) != 0;
     const int nst = nk - kt_begin;

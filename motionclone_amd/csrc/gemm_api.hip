@@ -11,11 +11,14 @@
 namespace mc {
 int gemm2_dispatch(const GemmParams& p, int mode, int small_tile, int deep, size_t rowsA, hipStream_t stream);   // gemm2.hip
 int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStream_t stream);                    // gemm3.hip
-int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream);                                         // gemm4.hip
+int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4Norm* norm = nullptr);          // gemm4.hip
 int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStream_t stream);                    // gemm5.hip
+int gn_partial_launch(const void* a, int lda, int ctot, int frames, int hw, float* partial, hipStream_t stream);   // norm.hip
 }  // namespace mc
 
 using namespace mc;
+
+extern "C" int mc_gn_nchunk(int hw);   // norm.hip
 
 #ifdef MC_TOOLS
 // TOOLS BUILD ONLY: timing experiments that drop parts of a GEMM kernel (GemmParams::dbg); results are garbage.
@@ -208,6 +211,39 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
         if (rc != MC_OK) return rc;
     }
     return MC_OK;
+}
+
+// ---- norm + GEMM in one launch (round 4) ------------------------------------------------------------------------------
+// C[M,N] = norm(A[M,320]) W[N,320]^T + bias with the normalisation applied in registers inside the streaming kernel
+// (gemm4.hip): kind 1 = LayerNorm (+ temporal position table), kind 2 = GroupNorm(32) without activation (one more launch:
+// the per-chunk partial sums).  MC_ERR_UNSUPPORTED = outside that kernel's shapes: the caller runs norm and GEMM separately.
+extern "C" int mc_norm_gemm_f16(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda,
+                                int ldc, int kind, const float* gamma, const float* beta, const float* pe, int hw,
+                                int nframes_pe, float eps, float* stats, float* partial, int flags, void* stream) {
+    if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C || !gamma || !beta) return MC_ERR_SHAPE;
+    if (kind != 1 && kind != 2) return MC_ERR_UNSUPPORTED;
+    if (K != 320 || N % 32 || (lda & 7) || (ldc & 7)) return MC_ERR_UNSUPPORTED;
+    const int epi = (flags & 0x200) ? 1 : 0;
+    if (epi && N % 64) return MC_ERR_UNSUPPORTED;
+    GemmParams p;
+    p.A = (const half_t*)A; p.A2 = nullptr; p.W = (const half_t*)W; p.C = (half_t*)C; p.R = nullptr; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.lda = lda; p.lda2 = 0; p.ldc = ldc; p.ldr = 0; p.c1 = K; p.ctot = K;
+    p.Hs = p.Ws = p.Ho = p.Wo = 0; p.rows_per_batch = M; p.alpha = 1.0f; p.epi = epi; p.s2_pad = 1;
+    p.ws = nullptr; p.splits = 1; p.dbg = 0;
+    G4Norm np{};
+    np.kind = kind; np.gamma = gamma; np.beta = beta; np.pe = kind == 1 ? pe : nullptr; np.hw = hw;
+    np.nframes_pe = nframes_pe; np.eps = eps; np.stats = stats;
+    hipStream_t s = (hipStream_t)stream;
+    if (kind == 2) {
+        if (hw <= 0 || M % hw || hw % 256 || !partial || !stats) return MC_ERR_UNSUPPORTED;
+        np.partial = partial;
+        np.nchunk = mc_gn_nchunk(hw);
+        np.gn_n = (float)hw * (K / 32);
+        int rc = gn_partial_launch(A, lda, K, M / hw, hw, partial, s);
+        if (rc != MC_OK) return rc;
+    }
+    g_last_kernel = 4;
+    return gemm4_dispatch(p, 0, s, &np);
 }
 
 // ---- split-K ------------------------------------------------------------------------------------------------------

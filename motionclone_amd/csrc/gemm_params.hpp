@@ -31,6 +31,20 @@ struct GemmParams {
     int dbg;    // timing experiments only (MC_GEMM_DEBUG): 1 = no global stores, 2 = no k-loop, 4 = no epilogue
 };
 
+// normalisation applied to the rows of A inside the K = 320 streaming kernel (gemm4.hip, mc_norm_gemm_f16)
+struct G4Norm {
+    int kind;               // 0 none, 1 LayerNorm, 2 per-frame affine
+    const float* gamma;
+    const float* beta;
+    const float* pe;        // kind 1: [nframes_pe][K] or null
+    int hw, nframes_pe;
+    float eps;
+    float* stats;           // kind 1: out [M][2] (mean, rstd) or null;  kind 2: out [frames][32][2]
+    const float* partial;   // kind 2: per-chunk (sum, sumsq) of gn_partial_kernel
+    int nchunk;
+    float gn_n;             // kind 2: elements per group (hw * channels per group)
+};
+
 constexpr int BK = 64;
 
 __device__ __forceinline__ int lds_off(int row, int v) {

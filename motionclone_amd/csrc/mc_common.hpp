@@ -190,6 +190,12 @@ __device__ __forceinline__ void raw_barrier() {
     asm volatile("" ::: "memory");
 }
 #endif
+// c + a.x b.x + a.y b.y with fp32 products and accumulation (v_dot2_f32_f16): row sums / sums of squares of fp16 data
+#ifdef MC_EMU
+__device__ inline float dot2acc(half2_t a, half2_t b, float c) { return c + (float)a[0] * (float)b[0] + (float)a[1] * (float)b[1]; }
+#else
+__device__ __forceinline__ float dot2acc(half2_t a, half2_t b, float c) { return __builtin_amdgcn_fdot2(a, b, c, false); }
+#endif
 // Identity the optimiser cannot see through: address arithmetic derived from the result is recomputed where it is used
 // instead of being hoisted out of a long loop and kept (or spilled) in VGPRs for its whole duration.
 #ifdef MC_EMU

@@ -256,29 +256,68 @@ class UNet3DEngine:
             return t[b * per:(b + 1) * per]
         return Geo(1, geo.F, geo.H, geo.W), cut
 
-    def _ff_geglu(self, n, prefix, geo, tape):
-        """FeedForward's first Linear + GEGLU on the normalised rows `n` -> (h * gelu(gate), taped pre-activation or None).
-        No backward: the product is formed in the GEMM epilogue and the [T, 8C] pre-activation never exists.  With a tape only
-        the differentiated batch element needs it: its rows take the unfused Linear + geglu kernel, the rows of the other batch
-        element (the unconditional half of a guided step) stay on the fused epilogue - half the geglu launches' bytes and
-        a third of that GEMM's output traffic gone."""
+    def _gn_gemm(self, x, gname, bname, wname, wbias, fr, hw):
+        """GroupNorm(32, eps 1e-6, no activation) + the 1x1 proj_in (attention.py:105-117, motion_module.py:145-151) ->
+        (proj_in output, GroupNorm statistics for the backward).  At the K = 320 level one launch for norm-apply + GEMM
+        (mc_norm_gemm_f16: the normalised tensor never reaches HBM), elsewhere GroupNorm then GEMM."""
         w = self.w
-        wname, bname = prefix + "ff.net.0.proj.weight", prefix + "ff.net.0.proj.bias"
+        gN, bN, W, bias = w.vec(gname), w.vec(bname), w.lin(wname), w.vec(wbias).unsqueeze(0)
+        r = ops.norm_gemm(x, W, 2, gN, bN, bias=bias, hw=hw, eps=1e-6)
+        if r is not None:
+            return r
+        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6)
+        return ops.gemm(hn, W, bias=bias), st
+
+    def _ln_gemm(self, h, gname, bname, W, tape, bias=None, pe=None, hw=0):
+        """LayerNorm (+ temporal position table) + Linear -> (output, (mean, rstd) per row or None without a tape)"""
+        w = self.w
+        g, b = w.vec(gname), w.vec(bname)
+        r = ops.norm_gemm(h, W, 1, g, b, bias=bias, pe=pe, hw=hw, save_stats=tape is not None)
+        if r is not None:
+            return r
+        n, ls = ops.layernorm_fwd(h, g, b, pe=pe, hw=hw, save_stats=tape is not None)
+        return ops.gemm(n, W, bias=bias), ls
+
+    def _ff_geglu(self, h, gname, bname, prefix, geo, tape):
+        """LayerNorm + FeedForward's first Linear + GEGLU on the rows `h` -> (h * gelu(gate), taped pre-activation or None,
+        LayerNorm statistics or None).  No backward: the product is formed in the GEMM epilogue and the [T, 8C] pre-activation
+        never exists.  With a tape only the differentiated batch element needs it: its rows take the unfused Linear + geglu
+        kernel, the rows of the other batch element (the unconditional half of a guided step) stay on the fused epilogue -
+        half the geglu launches' bytes and a third of that GEMM's output traffic gone.  At the K = 320 level the LayerNorm
+        runs inside the GEMMs (mc_norm_gemm_f16)."""
+        w = self.w
+        wname, biasname = prefix + "ff.net.0.proj.weight", prefix + "ff.net.0.proj.bias"
+        g, b = w.vec(gname), w.vec(bname)
+        T, gb = geo.T, (tape.grad_batch if tape is not None else None)
         if tape is None:
-            return ops.gemm(n, w.geglu_lin(wname), bias=w.geglu_vec(bname), geglu=True), None
-        gb = tape.grad_batch
-        if gb is None or geo.B == 1:
-            ff1 = ops.gemm(n, w.lin(wname), bias=w.vec(bname).unsqueeze(0))
-            return ops.geglu_fwd(ff1), ff1
-        T1 = geo.T // geo.B
-        gg = ops.empty((geo.T, w.lin(wname).shape[0] // 2), n)
-        lo, hi = gb * T1, (gb + 1) * T1
-        ff1 = ops.gemm(n[lo:hi], w.lin(wname), bias=w.vec(bname).unsqueeze(0))
+            r = ops.norm_gemm(h, w.geglu_lin(wname), 1, g, b, bias=w.geglu_vec(biasname), save_stats=False, geglu=True)
+            if r is not None:
+                return r[0], None, None
+            n, _ = ops.layernorm_fwd(h, g, b, save_stats=False)
+            return ops.gemm(n, w.geglu_lin(wname), bias=w.geglu_vec(biasname), geglu=True), None, None
+        T1 = T // geo.B
+        lo, hi = (0, T) if (gb is None or geo.B == 1) else (gb * T1, (gb + 1) * T1)
+        W1, b1 = w.lin(wname), w.vec(biasname).unsqueeze(0)
+        gg = ops.empty((T, W1.shape[0] // 2), h)
+        ls = ops.empty((T, 2), h, torch.float32)       # only rows lo .. hi (the differentiated batch element) are read later
+        r = ops.norm_gemm(h[lo:hi], W1, 1, g, b, bias=b1, stats=ls[lo:hi])
+        n = None
+        if r is not None:
+            ff1 = r[0]
+        else:                                          # outside the streaming kernel's shapes: LayerNorm, then the GEMMs
+            n, ls = ops.layernorm_fwd(h, g, b, save_stats=True)
+            ff1 = ops.gemm(n[lo:hi], W1, bias=b1)
         ops.geglu_fwd(ff1, out=gg[lo:hi])
-        for a, e in ((0, lo), (hi, geo.T)):
-            if e > a:
-                ops.gemm(n[a:e], w.geglu_lin(wname), bias=w.geglu_vec(bname), geglu=True, out=gg[a:e])
-        return gg, ff1
+        for a, e in ((0, lo), (hi, T)):
+            if e <= a:
+                continue
+            if n is None and ops.norm_gemm(h[a:e], w.geglu_lin(wname), 1, g, b, bias=w.geglu_vec(biasname), save_stats=False,
+                                           geglu=True, out=gg[a:e]) is not None:
+                continue
+            if n is None:
+                n, _ = ops.layernorm_fwd(h, g, b, save_stats=False)
+            ops.gemm(n[a:e], w.geglu_lin(wname), bias=w.geglu_vec(biasname), geglu=True, out=gg[a:e])
+        return gg, ff1, ls
 
     # ---- modules -----------------------------------------------------------------------------------
     def _resnet(self, p, x, x2, tb_all, geo, tape):
@@ -342,30 +381,23 @@ class UNet3DEngine:
         fr, hw, T = geo.frames, geo.hw, geo.T
         b = p + "transformer_blocks.0."
         gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
-        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6)
-        h0 = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
-        del hn
+        h0, st = self._gn_gemm(x, p + "norm.weight", p + "norm.bias", p + "proj_in.weight", p + "proj_in.bias", fr, hw)
         # self-attention
-        n1, ls1 = ops.layernorm_fwd(h0, w.vec(b + "norm1.weight"), w.vec(b + "norm1.bias"), save_stats=tape is not None)
-        qkv = ops.gemm(n1, w.cat_lin([b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"]))
-        del n1
+        qkv, ls1 = self._ln_gemm(h0, b + "norm1.weight", b + "norm1.bias",
+                                 w.cat_lin([b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"]), tape)
         a1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], hw, hw, heads, d, fr,
                                 need_lse=tape is not None)
         h1 = ops.gemm(a1, w.lin(b + "attn1.to_out.0.weight"), bias=w.vec(b + "attn1.to_out.0.bias").unsqueeze(0),
                       residual=h0)
         # cross-attention to the text (K/V are frame-invariant: computed once per batch element)
-        n2, ls2 = ops.layernorm_fwd(h1, w.vec(b + "norm2.weight"), w.vec(b + "norm2.bias"), save_stats=tape is not None)
-        q2 = ops.gemm(n2, w.lin(b + "attn2.to_q.weight"))
-        del n2
+        q2, ls2 = self._ln_gemm(h1, b + "norm2.weight", b + "norm2.bias", w.lin(b + "attn2.to_q.weight"), tape)
         kv = ops.gemm(text2d, w.cat_lin([b + "attn2.to_k.weight", b + "attn2.to_v.weight"]))
         a2, lse2 = ops.attn_fwd(q2, kv[:, :C], kv[:, C:], hw, n_text, heads, d, fr, kv_bdiv=geo.F,
                                 need_lse=tape is not None)
         h2 = ops.gemm(a2, w.lin(b + "attn2.to_out.0.weight"), bias=w.vec(b + "attn2.to_out.0.bias").unsqueeze(0),
                       residual=h1)
         # GEGLU feed-forward
-        n3, ls3 = ops.layernorm_fwd(h2, w.vec(b + "norm3.weight"), w.vec(b + "norm3.bias"), save_stats=tape is not None)
-        gg, bff1 = self._ff_geglu(n3, b, geo, tape)
-        del n3
+        gg, bff1, ls3 = self._ff_geglu(h2, b + "norm3.weight", b + "norm3.bias", b, geo, tape)
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
         out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)
@@ -417,18 +449,14 @@ class UNet3DEngine:
         b = p + "transformer_blocks.0."
         gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
         pe = w.pe(C)[:geo.F].contiguous()
-        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6)
-        h = ops.gemm(hn, w.lin(p + "proj_in.weight"), bias=w.vec(p + "proj_in.bias").unsqueeze(0))
-        del hn
+        h, st = self._gn_gemm(x, p + "norm.weight", p + "norm.bias", p + "proj_in.weight", p + "proj_in.bias", fr, hw)
         saved = []
         n_attn = 2 if (b + "attention_blocks.1.to_q.weight") in w.sd else 1   # SparseCtrl modules have one
         for a in range(n_attn):
             ap = b + "attention_blocks.%d." % a
             aname = ap[:-1]
-            n, ls = ops.layernorm_fwd(h, w.vec(b + "norms.%d.weight" % a), w.vec(b + "norms.%d.bias" % a), pe=pe, hw=hw,
-                                      save_stats=tape is not None)
-            qkv = ops.gemm(n, w.cat_lin([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]))
-            del n
+            qkv, ls = self._ln_gemm(h, b + "norms.%d.weight" % a, b + "norms.%d.bias" % a,
+                                    w.cat_lin([ap + "to_q.weight", ap + "to_k.weight", ap + "to_v.weight"]), tape, pe=pe, hw=hw)
             if record is not None and self._hooked(aname):   # the guidance read-out sees the differentiated batch element only
                 rg, rcut = self._bslice(geo, tape.grad_batch if tape is not None else None)
                 record[aname] = dict(qkv=rcut(qkv), C=C, heads=heads, d=d, geo=rg)
@@ -437,9 +465,7 @@ class UNet3DEngine:
             saved.append((h, ls, qkv, aname, ap))
             h = hnext
         h2 = h
-        n, lsf = ops.layernorm_fwd(h2, w.vec(b + "ff_norm.weight"), w.vec(b + "ff_norm.bias"), save_stats=tape is not None)
-        gg, bff1 = self._ff_geglu(n, b, geo, tape)
-        del n
+        gg, bff1, lsf = self._ff_geglu(h2, b + "ff_norm.weight", b + "ff_norm.bias", b, geo, tape)
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
         out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)

@@ -26,6 +26,7 @@ SIGNATURES = {
     "mc_workspace_bytes_attn_bwd": [I, I, I],
     "mc_workspace_bytes_tattn_loss": [I, I, I],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
+    "mc_norm_gemm_f16": [P, P, P, P, I, I, I, I, I, I, P, P, P, I, I, F, P, P, I, P],
     "mc_gemm_splitk_plan": [I, I, I, I],
     "mc_gemm_last_kernel": [],
     "mc_attn_last_kernel": [],
@@ -136,6 +137,23 @@ def workspace_bytes(op, *dims):
             raise RuntimeError("mc_workspace_bytes_%s%r: bad arguments" % (op, dims))
         _WS[key] = n
     return n
+
+
+def try_call(name, *args):
+    """like `call`, but MC_ERR_UNSUPPORTED (-2) is returned as False instead of raised: entry points that cover a subset of
+    the shapes (mc_norm_gemm_f16) let the caller fall back to the general launch sequence"""
+    if _lib is None or _FN.get("__lib__") is not _lib:
+        _FN.clear()
+        _FN["__lib__"] = load()
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib, name)
+    rc = fn(*args)
+    if rc == -2:
+        return False
+    if rc != 0:
+        raise RuntimeError("%s failed: %s (rc=%d)" % (name, ERRORS.get(rc, "unknown"), rc))
+    return True
 
 
 def call(name, *args):

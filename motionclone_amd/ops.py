@@ -230,6 +230,50 @@ def layernorm_bwd(dy, x, stats, gamma, add=None, out=None):
     return out
 
 
+# ---- norm + Linear in one launch (K = 320 level) -------------------------------------------------------
+NORM_GEMM_MIN_ROWS = 32768    # below this the streaming kernel does not fill the chip (gemm_api.hip's own rule for K = 320)
+
+
+def norm_gemm(x, w, kind, gamma, beta, *, bias=None, pe=None, hw=0, eps=1e-5, save_stats=True, geglu=False, out=None,
+              stats=None, force=False):
+    """LayerNorm (kind 1, + temporal position table `pe` [F, C]) or GroupNorm(32) without activation (kind 2, frames of `hw`
+    tokens) of the rows of x [M, 320], followed by the Linear w [N, 320] (+ bias [1, N]; geglu: fused GEGLU epilogue) - ONE
+    launch, the normalised rows never reach HBM (mc_norm_gemm_f16).  -> (out, stats), stats as layernorm_fwd / gn_fwd return
+    them (None for kind 1 without save_stats); or None when the shape is outside that kernel: the caller then runs the norm
+    and the GEMM separately.  `stats` (kind 1): write the row statistics into this [M, 2] fp32 view.  `force`: skip the
+    row-count rule (tests)."""
+    _f16(x), _f16(w)
+    M, K = x.shape
+    N = w.shape[0]
+    if K != 320 or w.shape[1] != K or N % 32 or (geglu and N % 64) or (M < NORM_GEMM_MIN_ROWS and not force):
+        return None
+    if kind == 2:
+        if hw <= 0 or M % hw or hw % 256:
+            return None
+        frames = M // hw
+        stats = empty((frames, 32, 2), x, torch.float32)
+        partial = workspace("groupnorm", x, frames, hw)
+    else:
+        if pe is not None and (hw <= 0 or hw % 256 or M % hw):
+            return None
+        if stats is not None:
+            assert stats.shape == (M, 2) and stats.dtype == torch.float32 and stats.is_contiguous()
+        elif save_stats:
+            stats = empty((M, 2), x, torch.float32)
+        partial = None
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = empty((M, n_out), x)
+    if bias is not None:
+        _f32(bias)
+        assert bias.shape[-1] == N and bias.numel() == N
+    ok = lib.try_call("mc_norm_gemm_f16", _p(x), _p(w), _p(out), _p(bias), M, N, K, _ld(x), _ld(out), kind,
+                      _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(pe)) if kind == 1 else None, hw,
+                      pe.shape[0] if (kind == 1 and pe is not None) else 0, float(eps), _p(stats), _p(partial),
+                      0x200 if geglu else 0, _stream(x))
+    return (out, stats) if ok else None
+
+
 # ---- spatial / cross attention ----------------------------------------------------------------------
 def attn_fwd(q, k, v, Nq, Nk, heads, d, nbatch, kv_bdiv=1, scale=None, need_lse=True, out=None):
     scale = d ** -0.5 if scale is None else scale

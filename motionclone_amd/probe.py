@@ -43,6 +43,14 @@ def _cost(name, a):
         nout = N // 2 if geglu else N
         nbytes = 2.0 * (rows_in * k_in + N * K + M * nout * (2 if a[4] else 1))
         return ("gemm", 2.0 * M * N * K, nbytes, (mode, M, N, K, geglu, bool(a[4])))
+    if name == "mc_norm_gemm_f16":
+        # (A, W, C, bias, M, N, K, lda, ldc, kind, gamma, beta, pe, hw, nframes_pe, eps, stats, partial, flags, stream)
+        M, N, K, kind, flags = a[4], a[5], a[6], a[9], a[18]
+        nout = N // 2 if flags & 0x200 else N
+        # algorithmic bytes of what it replaces and still has to move: A once (twice for GroupNorm: the statistics pass), W, C
+        nbytes = 2.0 * (M * K * (2 if kind == 2 else 1) + N * K + M * nout)
+        return ("gemm4<K=320 streaming> %s + DENSE" % ("LayerNorm" if kind == 1 else "GroupNorm"), 2.0 * M * N * K, nbytes,
+                (kind, M, N, K, bool(flags & 0x200)))
     if name == "mc_attn_fwd_f16":
         Nq, Nk, heads, d, nb = a[9], a[10], a[11], a[12], a[13]
         fl = 4.0 * Nq * Nk * d * heads * nb

@@ -154,3 +154,63 @@ def test_down_up_sample(setup):
         run_bwd(tape, out, cl(dout).to(dev))
         g = rel(uncl(tape.grads[id(xa)], B, F, H, W), gref)
         assert g < 2e-2, (kind, g)
+
+
+@pytest.fixture
+def setup320(backend, monkeypatch):
+    """level-0 width of SD-1.5 (C = 320, 8 heads of 40): the only width where the norms run inside the K = 320 streaming GEMM
+    (mc_norm_gemm_f16); the row-count rule is lifted so that the fused launches are taken at test size"""
+    cfg = dict(U.TINY_CONFIG, block_out_channels=(320, 128, 128, 128), attention_heads=8, motion_heads=8)
+    sd = {k: v.half().float() for k, v in U.random_state_dict(cfg, seed=6).items()}
+    monkeypatch.setattr(ops, "NORM_GEMM_MIN_ROWS", 0)
+    calls = []
+    real = ops.norm_gemm
+
+    def counting(*a, **k):
+        r = real(*a, **k)
+        calls.append((a[2], r is not None))
+        return r
+    monkeypatch.setattr(ops, "norm_gemm", counting)
+    return backend, cfg, sd, E.UNet3DEngine(sd, cfg, backend), calls
+
+
+@pytest.mark.parametrize("grad_batch", [None, 1, "inference"])
+def test_level0_modules_with_the_norms_inside_the_gemm(setup320, grad_batch):
+    """_spatial and _motion at C = 320 with GroupNorm + proj_in, LayerNorm + q|k|v / q / FeedForward (+ GEGLU, + the temporal
+    position table) each as ONE launch: forward and data-gradient against the oracle; with a sliced tape (grad_batch = 1, the
+    guided step's B = 2 forward) the differentiated rows take LayerNorm + Linear fused and the others LayerNorm + GEGLU fused"""
+    dev, cfg, sd, eng, calls = setup320
+    B, F, H, W, C = 2, 2, 16, 16, 320
+    geo = E.Geo(B, F, H, W)
+    x = rnd((B, C, F, H, W), 1)
+    text = rnd((B, 7, cfg["cross_attention_dim"]), 2)
+    for kind in ("spatial", "motion"):
+        del calls[:]
+        tape = None if grad_batch == "inference" else E.Tape(grad_batch=grad_batch)
+        xa = cl(x).to(dev)
+        xin = x.float().requires_grad_()
+        if kind == "spatial":
+            name = "down_blocks.0.attentions.0."
+            out = eng._spatial(name, xa, text.reshape(B * 7, -1).to(dev), 7, geo, tape)
+            ref = U.spatial_transformer(sd, name, xin, text.float(), cfg)
+            want_calls = 4 if grad_batch != 1 else 5      # GroupNorm, 3 LayerNorms (the FeedForward one twice when sliced)
+        else:
+            name = "down_blocks.0.motion_modules.0"
+            out = eng._motion(name, xa, geo, tape, None, None)
+            ref = U.motion_module(sd, name + ".", xin, cfg, None, name)
+            want_calls = 4 if grad_batch != 1 else 5
+        assert len(calls) == want_calls and all(ok for _, ok in calls), calls
+        assert [k for k, _ in calls].count(2) == 1          # the GroupNorm + proj_in launch among them
+        assert rel(uncl(out, B, F, H, W), ref) < 1e-2, kind
+        if tape is None:
+            continue
+        dout = rnd(tuple(ref.shape), 4)
+        (gref,) = torch.autograd.grad(ref, xin, dout.float())
+        d = cl(dout).to(dev)
+        if grad_batch is not None:
+            T1 = geo.T // B
+            d, gref = d[grad_batch * T1:(grad_batch + 1) * T1].contiguous(), gref[grad_batch:grad_batch + 1]
+        run_bwd(tape, out, d)
+        got = tape.grads[id(xa)]
+        g = rel(uncl(got, 1 if grad_batch is not None else B, F, H, W), gref)
+        assert g < 2e-2, (kind, g)

@@ -106,7 +106,7 @@ def test_graph_replay_matches_eager(full):
     for i in (0, 25):
         want1 = smp.step(lat, i, text, rep_dev)
         want2 = smp.step(lat2, i, text, rep_dev)
-        got_first = smg.step(lat, i, text, rep_dev)            # eager + capture
+        got_first = smg.step(lat, i, text, rep_dev).clone()    # capture + first replay: the graph's static output buffer
         got1 = smg.step(lat, i, text, rep_dev).clone()         # replay
         got2 = smg.step(lat2, i, text, rep_dev).clone()        # replay with another latent
         assert torch.equal(got_first, want1) and torch.equal(got1, want1) and torch.equal(got2, want2)

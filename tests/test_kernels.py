@@ -734,3 +734,45 @@ def test_top1_follows_the_reference_fp16_order_bit_exactly(backend, F_, d):
     assert tie_rows.any(), "the duplicated key frame should have produced exact ties"
     print("top1 bit-exact on %d of %d rows (%d differ, all on an fp16 rounding boundary; %d rows near one), %d exact with ties"
           % (int((~bad).sum()), bad.numel(), int(bad.sum()), int(amb.sum()), int(tie_rows.sum())))
+
+
+@pytest.mark.parametrize("kind,N,geglu,with_pe", [(1, 320, False, False), (1, 960, False, True), (1, 640, True, False),
+                                                  (2, 320, False, False), (2, 128, True, False)])
+def test_norm_gemm_equals_norm_then_gemm(backend, kind, N, geglu, with_pe):
+    """mc_norm_gemm_f16 (round 4): LayerNorm (+ position table) / GroupNorm-without-activation applied to the rows of A in
+    registers inside the K = 320 streaming GEMM, against the two-launch form it replaces (same arithmetic, one fp16 rounding
+    of the normalised value; the statistics agree to fp32 rounding) and against fp32 torch.  M = 3 frames x 256 tokens with a
+    ragged last workgroup for LayerNorm."""
+    dev = backend
+    K, hw = 320, 256
+    M = 3 * hw if (kind == 2 or with_pe) else 3 * hw - 40
+    x = (rnd((M, K), dev, 1) * 1.5 + 0.3).half()
+    w = (rnd((N, K), dev, 2) * 0.05).half()
+    bias = rnd((1, N), dev, 3).float() * 0.1
+    gamma, beta = 1.0 + 0.2 * rnd((K,), dev, 4).float(), 0.1 * rnd((K,), dev, 5).float()
+    pe = rnd((4, K), dev, 6).float() if with_pe else None
+    if geglu:
+        wi, bi = ops.interleave_geglu(w).contiguous(), ops.interleave_geglu(bias.reshape(-1)).reshape(1, -1).contiguous()
+    else:
+        wi, bi = w, bias
+    got = ops.norm_gemm(x, wi, kind, gamma, beta, bias=bi, pe=pe, hw=hw, eps=1e-5, geglu=geglu, force=True)
+    assert got is not None, "the fused kernel refused a shape it is specified for"
+    out, stats = got
+    if kind == 1:
+        n, ls = ops.layernorm_fwd(x, gamma, beta, eps=1e-5, pe=pe, hw=hw)
+        xf = x.float()
+        ref_n = torch.nn.functional.layer_norm(xf, (K,), gamma, beta, 1e-5)
+        if pe is not None:
+            ref_n = ref_n + pe[(torch.arange(M, device=dev) // hw) % 4]
+    else:
+        n, ls = ops.gn_fwd(x, None, gamma, beta, False, M // hw, hw, 1e-5)
+        xr = x.float().reshape(M // hw, hw, K).permute(0, 2, 1)
+        ref_n = torch.nn.functional.group_norm(xr, 32, gamma, beta, 1e-5).permute(0, 2, 1).reshape(M, K)
+    two = ops.gemm(n, wi, bias=bi, geglu=geglu)
+    close(stats, ls, 1e-4, 1e-4, "statistics vs the separate norm kernel")
+    close(out, two, 4e-3, 4e-3, "fused vs norm kernel + GEMM")
+    y = ref_n.half().float() @ w.float().t() + bias
+    if geglu:
+        y = y[:, :N // 2] * torch.nn.functional.gelu(y[:, N // 2:])
+    close(out, y, 1e-2, 1e-2, "fused vs fp32 torch")
+    assert ops.norm_gemm(x[:, :256].contiguous(), wi[:, :256].contiguous(), kind, gamma[:256], beta[:256], force=True) is None
