@@ -28,23 +28,34 @@
 namespace mc {
 
 namespace g5 {
-constexpr int BN = 320, NW = 8, NT = 512, TN = 5, BKT = 32, NS = 4;
+constexpr int BN = 320, NW = 8, NT = 512, TN = 5, BKT = 32, NS = 4;   // the 8-wave geometries (defaults of Tile<>)
 constexpr int ROWB = 64;                 // bytes per staged row (32 halfs)
 constexpr int RPI = 16;                  // rows moved by one LDS-DMA instruction
 constexpr int RS = 336;                  // row pitch of the epilogue's fp16 image (bytes)
 constexpr int RSG = 176;                 // same, fused GEGLU (80 outputs per row)
 constexpr int STG = 32 * RS;             // one 32-row block of a wave's tile
-// BM = 256: wave tile 64 x 160 (two 32-row blocks); BM = 128: 32 x 160 - same 8 waves, for problems that do not fill the
-// 256 CUs with 256-row tiles (the 16x16 / 8x8 levels); more LDS and L2 traffic per MFMA, still two waves per SIMD
-template <int BM>
+// Geometries (wave tile = 32 TM rows x 160 columns of v_mfma_f32_32x32x16_f16, TN = 5 column blocks):
+//   <256, 320, 8, 4>  8 waves as 4 x 2, wave tile 64 x 160, ring of 4 stages (144 KiB): ONE workgroup per CU - the default
+//   <128, 320, 8, 4>  8 waves, wave tile 32 x 160: problems that do not fill the 256 CUs with 256-row tiles (16x16 / 8x8 levels)
+//   <256, 160, 4, 3>  (round 4) 4 waves as 4 x 1, wave tile 64 x 160, ring of 3 stages (78 KiB): TWO workgroups per CU that
+//                     run out of step - one tile's prologue / epilogue (residual read, stores) under the other's k-loop.  Same
+//                     per-wave code as the default (TM = 2), 1.44x the operand bytes per MFMA (A is fetched once per 160
+//                     columns instead of once per 320).  For the short-K launches of about one wave of tiles.
+template <int BM, int BN_ = BN, int NW_ = NW, int NS_ = NS>
 struct Tile {
-    static constexpr int TM = BM / 128;
-    static constexpr int RA = BM / RPI / NW;             // activation row groups per wave and stage
-    static constexpr int STAGE = (BM + BN) * ROWB;       // 36864 / 28672
+    static constexpr int BNT = BN_, NWV = NW_, NSV = NS_, NTH = NW_ * 64;
+    static constexpr int WNW = BN_ / 160, WMW = NW_ / WNW;   // waves along N / along M
+    static constexpr int TM = BM / (32 * WMW);
+    static constexpr int RA = BM / RPI / NW_;            // activation row groups per wave and stage
+    static constexpr int WB = (BN_ / RPI) / NW_;         // weight row groups every wave moves per stage ...
+    static constexpr int WX = (BN_ / RPI) % NW_;         // ... and the first WX waves one more
+    static constexpr int STAGE = (BM + BN_) * ROWB;      // 36864 / 28672 / 26624
     static constexpr int A_BYTES = BM * ROWB;
-    static constexpr int LB = RA + 2, LA = RA + 3;       // LDS-DMA instructions per stage: waves 4-7 / waves 0-3 (one more weight group)
-    static constexpr size_t SMEM = (size_t)NS * STAGE;
-    static_assert(BM % 128 == 0 && NW * STG <= NS * STAGE, "epilogue image must fit the ring");
+    static constexpr int LB = RA + WB, LA = RA + WB + 1; // LDS-DMA instructions per stage: waves >= WX / waves < WX
+    static constexpr size_t SMEM = (size_t)NS_ * STAGE;
+    static_assert(BN_ % 160 == 0 && NW_ % WNW == 0 && BM % (32 * WMW) == 0 && BM % (RPI * NW_) == 0, "tile / wave grid");
+    static_assert(WX > 0 && NW_ * STG <= NS_ * STAGE, "epilogue image must fit the ring");
+    static_assert(NS_ == 3 || NS_ == 4, "ring depth");
 };
 
 __device__ __forceinline__ int lds_off32(int row, int v) { return row * 64 + ((v ^ ((row >> 2) & 3)) << 4); }
@@ -128,12 +139,13 @@ __device__ __forceinline__ void g5_epilogue(const GemmParams& p, f32x16 (&acc)[g
 // VAR (timing experiments, tools/gemm5_bench.py): bit 0 = STAGGER the LDS-DMA issue between the two waves of a SIMD (waves 0-3
 // in the first half of a stage, waves 4-7 in the second; measured 1-8 % slower than everybody in the first half, which is the
 // default), bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
-template <int MODE, int EPI, int VAR, int BM>
-__global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2, uint32_t bytesW,
-                                                        int tilesM, int tilesN, int sm, int sn) {
-    using namespace g5;
-    using T = Tile<BM>;
-    constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB;
+template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
+                                                                          uint32_t bytesW, int tilesM, int tilesN, int sm, int sn) {
+    using g5::TN; using g5::BKT; using g5::RPI; using g5::STG; using g5::lds_off32;
+    using T = g5::Tile<BM, BN, NW, NS>;
+    constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB, WB = T::WB, WX = T::WX;
+    constexpr int WMW = T::WMW;
     MC_DYN_SMEM(smem);
 
     const int tid = threadIdx.x;
@@ -143,7 +155,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
 #else
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform: scalar branches on the wave group
 #endif
-    const bool grpA = wave < 4;
+    const bool grpA = wave < WX;     // the waves that move one more weight row group per stage
     const int pid = blockIdx.x;
     const int xcd = pid & 7, local = pid >> 3;   // workgroup b runs on XCD b % 8 (observed; a speed assumption only)
     int tm, tn;
@@ -193,11 +205,11 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
             a_ox[i] = rem - oy * p.Wo;
         }
     }
-    // weight row groups: 20 per stage; wave w takes w, w + 8 and (waves 0-3) 16 + w
-    uint32_t w_off[3];
+    // weight row groups: BN / 16 per stage; wave w takes w, w + NW, ... (WB of them) and (waves < WX) WB NW + w
+    uint32_t w_off[WB + 1];
 #pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        int n = n0 + (i < 2 ? wave + NW * i : 16 + (wave & 3)) * RPI + rsub;
+    for (int i = 0; i <= WB; ++i) {
+        int n = n0 + (i < WB ? wave + NW * i : WB * NW + (wave % WX)) * RPI + rsub;
         w_off[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)lslot * 16u : kOOB;
     }
 
@@ -255,7 +267,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
         } else {
             const int i = piece - RA;
             uint32_t voff = w_off[i] + (uint32_t)kt * (BKT * 2u);   // kOOB + a small offset stays out of range
-            glds16(bufW, voff, base + A_BYTES + (i < 2 ? wave + NW * i : 16 + (wave & 3)) * 1024);
+            glds16(bufW, voff, base + A_BYTES + (i < WB ? wave + NW * i : WB * NW + (wave % WX)) * 1024);
         }
     };
     auto issue_stage = [&](int kt, int buf) {
@@ -263,11 +275,11 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
         for (int q = 0; q < LB; ++q) issue_piece(kt, buf, q);
         if (grpA) issue_piece(kt, buf, LB);
     };
-    // wait until at most `tiles` (0..2) of this wave's staged tiles are still in flight (loads retire in order)
+    // wait until at most `tiles` (0 .. NS - 2) of this wave's staged tiles are still in flight (loads retire in order)
     auto wait_tiles = [&](int tiles) {
         if (tiles <= 0) {
             wait_vmcnt_le<0>();
-        } else if (tiles == 1) {
+        } else if (tiles == 1 || NS == 3) {
             if (grpA) wait_vmcnt_le<LA>(); else wait_vmcnt_le<LB>();
         } else {
             if (grpA) wait_vmcnt_le<2 * LA>(); else wait_vmcnt_le<2 * LB>();
@@ -282,7 +294,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int wr = wave & 3, wc = wave >> 2;
+    const int wr = wave % WMW, wc = wave / WMW;
     const int wm0 = wr * (32 * TM), wn0 = wc * 160;
     const int l31 = lane & 31, lhi = lane >> 5;
 
@@ -295,11 +307,12 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     // first operand stage, so that the epilogue's lockstep read finds them in L2 / the Infinity Cache: every +R shape got
     // SLOWER inside the step loop - 32768 x 640 x 640 52.7 -> 57.0 us, 131072 x 320 x 1280 162 -> 175 us, the convs +3 % -
     // 34.6 vs 34.8 videos/min.  The rows compete with the operand stream for the same L2 while the k-loop runs.)
-    // prologue: waves 0-3 put stages 0..2 in flight, waves 4-7 stages 0..3 (they issue stage j + 4 in the second half of j)
-    const bool stagger = (VAR & 1) != 0;
+    // prologue: NS - 1 stages in flight (experiment VAR bit 0, ring of four only: waves 4-7 put a fourth one in flight - they
+    // issue stage j + 4 in the second half of j)
+    const bool stagger = NS == 4 && (VAR & 1) != 0;
     const int nst = nk - kt_begin;
 #pragma unroll
-    for (int s0 = 0; s0 < 3; ++s0)
+    for (int s0 = 0; s0 < NS - 1; ++s0)
         if (s0 < nst) issue_stage(kt_begin + s0, s0);
     if (stagger && !grpA && 3 < nst) issue_stage(kt_begin + 3, 3);
 
@@ -319,9 +332,10 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     //   read a'0 [, a'1];  then for each weight fragment i:  MFMA (i,0) [, (i,1)], read w'i, [one LDS-DMA]
     // A weight fragment is dead after its MFMAs, so w'i can take its registers: 5 + 2 TM fragments live instead of
     // 2 x (5 + TM) (the 256-register budget holds 160 accumulators at TM = 2), and no instruction kind is issued in a burst.
-    auto half_step = [&](auto nl_tag, int rbuf, int rks, half8_t* ra, half8_t* rw, const half8_t* ca, const half8_t* cw,
+    auto half_step = [&](auto nl_tag, auto p0_tag, int rbuf, int rks, half8_t* ra, half8_t* rw, const half8_t* ca, const half8_t* cw,
                          int lkt, int lbuf) {
-        constexpr int NL = decltype(nl_tag)::value;
+        constexpr int NL = decltype(nl_tag)::value;      // LDS-DMA instructions woven into this half ...
+        constexpr int P0 = decltype(p0_tag)::value;      // ... pieces P0 .. P0 + NL - 1 of the stage
         static_assert(NL <= TN, "one LDS-DMA behind each weight fragment at most");
         const char* bA = smem + rbuf * STAGE;
         const char* bW = bA + A_BYTES;
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
 #pragma unroll
             for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(cw[i], ca[j], acc[i][j]);
             rw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * rks + lhi));
-            if (i < NL) issue_piece(lkt, lbuf, i);
+            if (i < NL) issue_piece(lkt, lbuf, P0 + i);
         }
 #ifndef MC_EMU
         __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);          // DS read: a'0 [, a'1]
@@ -346,13 +360,19 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
         }
 #endif
     };
+    // a stage's LA / LB pieces: the first TN at most behind the weight fragments of the stage's first half, the rest (the
+    // 4-wave geometry moves 6 / 7 per wave and stage) behind those of its second half
+    constexpr int A1 = LA < TN ? LA : TN, A2 = LA - A1, B1 = LB < TN ? LB : TN, B2 = LB - B1;
     using N0 = std::integral_constant<int, 0>;
+    using NA1 = std::integral_constant<int, A1>;
+    using NA2 = std::integral_constant<int, A2>;
+    using NB1 = std::integral_constant<int, B1>;
+    using NB2 = std::integral_constant<int, B2>;
     using NLB = std::integral_constant<int, LB>;
-    using NLA = std::integral_constant<int, LA>;
 
     // stage 0 landed: this wave's own loads (counted: waves 4-7 may have three younger stages in flight), then everybody's
     {
-        const int younger = min(stagger && !grpA ? 3 : 2, nst - 1);
+        const int younger = min(stagger && !grpA ? 3 : NS - 2, nst - 1);
         if (younger >= 3) wait_vmcnt_le<3 * LB>(); else wait_tiles(younger);
     }
     raw_barrier();
@@ -361,46 +381,50 @@ __global__ __launch_bounds__(512, 1) void gemm5_kernel(GemmParams p, uint32_t by
     // The loop is written out per wave group and per phase (steady state / tail) so that each body is one straight-line
     // scheduling region with a fixed instruction mix; every version executes exactly one barrier per stage.
     int buf = 0, kt = kt_begin;
+    constexpr int PD = NS - 1;       // prefetch distance in stages
+    auto nxt = [](int b) { return b + 1 == NS ? 0 : b + 1; };
+    auto slot_of_new = [](int b) { return b == 0 ? NS - 1 : b - 1; };   // the slot freed at the previous barrier = (b + NS - 1) % NS
     if (grpA) {
-        // steady state of waves 0-3: stage kt + 3 goes into the slot freed at the previous barrier
-        for (; kt + 3 < nk; ++kt) {
-            const int nbuf = (buf + 1) & 3;
-            half_step(NLA(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
-            // stage kt + 1 landed (own loads: counted wait, two younger stages stay in flight; everybody's: barrier).  Past
-            // the barrier every wave has also finished reading stage kt (slice-1 fragments are in registers)
-            wait_vmcnt_le<2 * LA>();
+        // steady state of the waves with LA pieces: stage kt + PD goes into the slot freed at the previous barrier
+        for (; kt + PD < nk; ++kt) {
+            const int nbuf = nxt(buf), lbuf = slot_of_new(buf);
+            half_step(NA1(), N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + PD, lbuf);
+            // stage kt + 1 landed (own loads: counted wait - NS - 3 younger stages and the pieces just issued stay in flight;
+            // everybody's: barrier).  Past the barrier every wave has also finished reading stage kt (slice-1 fragments are
+            // in registers)
+            wait_vmcnt_le<(NS - 3) * LA + A1>();
             raw_barrier();
-            half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
+            half_step(NA2(), NA1(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + PD, lbuf);
             buf = nbuf;
         }
     } else if (!stagger) {
-        // waves 4-7: the same with one weight row group less
-        for (; kt + 3 < nk; ++kt) {
-            const int nbuf = (buf + 1) & 3;
-            half_step(NLB(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + 3, (buf + 3) & 3);
-            wait_vmcnt_le<2 * LB>();
+        // the other waves: the same with one weight row group less
+        for (; kt + PD < nk; ++kt) {
+            const int nbuf = nxt(buf), lbuf = slot_of_new(buf);
+            half_step(NB1(), N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], kt + PD, lbuf);
+            wait_vmcnt_le<(NS - 3) * LB + B1>();
             raw_barrier();
-            half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
+            half_step(NB2(), NB1(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + PD, lbuf);
             buf = nbuf;
         }
-    } else {
-        // experiment (VAR bit 0): waves 4-7 issue stage kt + 4 into slot `buf` right after the barrier that frees it
+    } else if constexpr (NS == 4 && LB <= TN) {
+        // experiment (VAR bit 0, ring of four): waves 4-7 issue stage kt + 4 into slot `buf` right after the barrier that frees it
         for (; kt + 4 < nk; ++kt) {
-            const int nbuf = (buf + 1) & 3;
-            half_step(N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
+            const int nbuf = nxt(buf);
+            half_step(N0(), N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
             wait_vmcnt_le<2 * LB>();
             raw_barrier();
-            half_step(NLB(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + 4, buf);
+            half_step(NLB(), N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], kt + 4, buf);
             buf = nbuf;
         }
     }
     // tail: nothing left to issue (the next stage's slice-0 fragments read after the last stage are stale and never used)
     for (; kt < nk; ++kt) {
-        const int nbuf = (buf + 1) & 3;
-        half_step(N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
-        wait_tiles(min(2, nk - 2 - kt));
+        const int nbuf = nxt(buf);
+        half_step(N0(), N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], 0, 0);
+        wait_tiles(min(NS - 2, nk - 2 - kt));
         raw_barrier();
-        half_step(N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
+        half_step(N0(), N0(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], 0, 0);
         buf = nbuf;
     }
     // every wave passed the last barrier after its final LDS read and no load is in flight: the ring is free
@@ -464,13 +488,15 @@ __global__ __launch_bounds__(64) void splitk_reduce5_kernel(GemmParams p, int ti
     g5_epilogue<0, TM>(p, acc, smem, tm * (128 * TM) + wr * (32 * TM), tn * BN + wc * 160, lane);
 }
 
-template <int MODE, int EPI, int VAR, int BM>
+template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS>
 static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
-    using T = g5::Tile<BM>;
-    int tM = (p.M + BM - 1) / BM, tN = (p.N + g5::BN - 1) / g5::BN;
-    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM>, T::SMEM);
-    // super-tile of the XCD-local tile order: sn divides the N-tiles, sm x sn ~ 32 workgroups, least operand rows per tile
+    using T = g5::Tile<BM, BN, NW, NS>;
+    int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
+    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS>, T::SMEM);
+    // super-tile of the XCD-local tile order: sn divides the N-tiles, sm x sn ~ the workgroups an XCD holds at a time (32 CUs x
+    // 1 or 2), least operand rows per tile
     const int rows_per_xcd = (tM + 7) / 8;
+    const int resident = NW == 8 ? 32 : 64;
     int sm = 1, sn = 1;
     static const int no_swz = MC_ENV_INT("MC_GEMM5_NO_SUPERTILE", 0);   // A/B only
     // a weight matrix that fits the XCD's 4 MiB L2 beside the streaming activations is reused ACROSS M-tiles by the old order
@@ -480,25 +506,36 @@ static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, 
         long best = -1;
         for (int c = 1; c <= tN && c <= 16; ++c) {
             if (tN % c) continue;
-            int r = std::max(1, std::min(rows_per_xcd, (32 + c / 2) / c));
-            long cost = ((long)r * BM + (long)c * g5::BN) * 1000 / ((long)r * c);   // operand rows fetched per tile of the super-tile
+            int r = std::max(1, std::min(rows_per_xcd, (resident + c / 2) / c));
+            long cost = ((long)r * BM + (long)c * BN) * 1000 / ((long)r * c);   // operand rows fetched per tile of the super-tile
             if (best < 0 || cost < best) best = cost, sm = r, sn = c;
         }
     }
     const int groups = (rows_per_xcd + sm - 1) / sm;
     dim3 grid((unsigned)(groups * sm * 8 * tN), (unsigned)p.splits);
-    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM>), grid, dim3(g5::NT), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
+    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS>), grid, dim3(T::NTH), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
     if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
-    if (p.ws) {
-        MC_LAUNCH((splitk_reduce5_kernel<T::TM>), dim3((unsigned)(tM * tN * g5::NW)), dim3(64), (size_t)g5::STG, stream, p, tM, tN);
-        if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
+    if constexpr (NW == 8 && BN == g5::BN) {   // (the split-K slabs / reduce pass are laid out for the 8-wave geometries)
+        if (p.ws) {
+            MC_LAUNCH((splitk_reduce5_kernel<T::TM>), dim3((unsigned)(tM * tN * g5::NW)), dim3(64), (size_t)g5::STG, stream, p, tM, tN);
+            if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
+        }
     }
     return MC_OK;
 }
 
-// var: 0 = shipped schedule, 256-row tiles; 1 / 2 / 3 = schedule experiments (dense and stride-1 conv); 4 = 128-row tiles
+// var: 0 = shipped schedule, 256-row tiles; 1 / 2 / 3 = schedule experiments (dense and stride-1 conv); 4 = 128-row tiles;
+// 5 = 256 x 160 tiles, 4 waves, ring of three: two workgroups per CU (dense only, no split-K)
 template <int MODE>
 static int launch5_var(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, int var, hipStream_t s) {
+    if (var == 5) {
+        if constexpr (MODE == DENSE) {
+            if (p.ws || p.N % 160) return MC_ERR_UNSUPPORTED;
+            if (p.epi == 1) return launch5<DENSE, 1, 0, 256, 160, 4, 3>(p, bA, bA2, bW, s);
+            return launch5<DENSE, 0, 0, 256, 160, 4, 3>(p, bA, bA2, bW, s);
+        }
+        return MC_ERR_UNSUPPORTED;
+    }
     if (p.epi == 1) {
         if (MODE != DENSE) return MC_ERR_UNSUPPORTED;
         return var == 4 ? launch5<DENSE, 1, 0, 128>(p, bA, bA2, bW, s) : launch5<DENSE, 1, 0, 256>(p, bA, bA2, bW, s);
@@ -522,6 +559,7 @@ int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStre
     if (bytesA > lim || bytesA2 > lim || bytesW > lim) return MC_ERR_UNSUPPORTED;
     if ((p.ws != nullptr) != (p.splits > 1)) return MC_ERR_UNSUPPORTED;
     if (p.ws && (p.epi == 1 || (var != 0 && var != 4))) return MC_ERR_UNSUPPORTED;
+    if (var == 5 && mode != DENSE) return MC_ERR_UNSUPPORTED;
     if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
     if (p.epi == 1 && (p.N & 15)) return MC_ERR_UNSUPPORTED;
     switch (mode) {

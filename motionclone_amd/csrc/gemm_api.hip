@@ -18,6 +18,10 @@ int gn_partial_launch(const void* a, int lda, int ctot, int frames, int hw, floa
 
 using namespace mc;
 
+#ifndef MC_GEMM5_2WG_DEFAULT
+#define MC_GEMM5_2WG_DEFAULT 0     // measured choice of the product library (profiles/r04_gemm5_2wg.md)
+#endif
+
 extern "C" int mc_gn_nchunk(int hw);   // norm.hip
 
 #ifdef MC_TOOLS
@@ -58,6 +62,10 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         g_last_kernel = big_cfg == 15 ? 54 : 51;
         return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);
     }
+    if (big_cfg == 9) {    // gemm5 with 256 x 160 tiles, 4 waves, two workgroups per CU
+        g_last_kernel = 56;
+        return gemm5_dispatch(p, mode, 5, rowsA, s);
+    }
     static const int no_g5 = MC_ENV_INT("MC_NO_GEMM5", 0);     // A/B, tools build only
     static const int g5_var = MC_ENV_INT("MC_GEMM5_VAR", 0);   // A/B, tools build only
     const bool automatic = !big_cfg && !tile && !deep;   // an explicit cfg = 1 still means gemm3 (tests, A/B tools)
@@ -84,6 +92,21 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
                 big_cfg = 4;
                 onewave_g3 = onewave128 == 2;   // 2: on gemm3's geometry (two 4-wave workgroups per CU, free to fall out of step)
             }
+        }
+    }
+    // 256 x 160 tiles, 4 waves, TWO workgroups per CU (gemm5.hip, round 4).  G5_2WG: 0 = never, 1 = dense launches of about
+    // one wave of 256 x 320 tiles, 2 = every dense launch with K <= 1280, 3 = every dense launch, 4 = wide short-K launches
+    // (tools build: MC_GEMM5_2WG)
+    static const int two_wg = MC_ENV_INT("MC_GEMM5_2WG", MC_GEMM5_2WG_DEFAULT);
+    if (big_cfg == 1 && automatic && !no_g5 && two_wg && mode == DENSE && N % 160 == 0) {
+        const long b1 = (long)((M + 255) / 256) * (N / 320);
+        // 4 = the shapes that gained inside the step loop (profiles/r04_gemm5_2wg.md): wide outputs (>= 12 column tiles of
+        // 160), short K, enough rows for both workgroups of every CU
+        const bool wide_short = N >= 1920 && p.K <= 1280 && M >= 8192;
+        if (two_wg == 3 || (two_wg == 2 && p.K <= 1280) || (two_wg == 1 && b1 <= 320) || (two_wg == 4 && wide_short)) {
+            int rc5 = gemm5_dispatch(p, mode, 5, rowsA, s);
+            g_last_kernel = 56;
+            if (rc5 != MC_ERR_UNSUPPORTED) return rc5;
         }
     }
     if (big_cfg == 1 && automatic && !no_g5) {

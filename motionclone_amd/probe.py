@@ -21,7 +21,7 @@ PEAK_TFLOPS = 2500.0     # fp16 dense MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0   # spec; achievable ~6300
 
 _GEMM_KERNELS = {2: "gemm2<128x128>", 20: "gemm2<64x64>", 4: "gemm4<K=320 streaming>", 51: "gemm5<256x320>",
-                 54: "gemm5<128x320>"}
+                 54: "gemm5<128x320>", 56: "gemm5<256x160 x2 per CU>"}
 _MODES = ["DENSE", "CONV_S1", "CONV_S2", "CONV_UP", "TCONV_S2"]
 
 

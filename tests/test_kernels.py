@@ -776,3 +776,30 @@ def test_norm_gemm_equals_norm_then_gemm(backend, kind, N, geglu, with_pe):
         y = y[:, :N // 2] * torch.nn.functional.gelu(y[:, N // 2:])
     close(out, y, 1e-2, 1e-2, "fused vs fp32 torch")
     assert ops.norm_gemm(x[:, :256].contiguous(), wi[:, :256].contiguous(), kind, gamma[:256], beta[:256], force=True) is None
+
+
+def test_gemm5_two_workgroups_per_cu_geometry(backend):
+    """gemm5 with 256 x 160 tiles, 4 waves, ring of three stages (cfg = 9, round 4): two workgroups per CU out of step.  Dense
+    with per-batch bias / residual / alpha, M and N tails, K of 2, 4, 6 stages (ring not yet full) and 20 / 40, fused GEGLU;
+    the same sums in the same order as the 8-wave kernel (a wave tile is 64 x 160 in both), so the two agree bit for bit."""
+    dev = backend
+    shapes = [(300, 320, 64), (260, 640, 128), (520, 480, 192), (300, 160, 640)] if not big(dev) else \
+        [(3000, 960, 64), (5000, 640, 1280), (32768, 640, 640), (4111, 1120, 192)]
+    for (M, N, K) in shapes:
+        a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+        bias = torch.randn(2, N, generator=torch.Generator().manual_seed(3)).to(dev)
+        res = rnd((M, N), dev, 4)
+        rpb = (M + 1) // 2
+        out = ops.gemm(a, w, bias=bias, residual=res, alpha=0.5, rows_per_batch=rpb, cfg=9)
+        lin = (0.5 * (a.float() @ w.float().t()) + bias.repeat_interleave(rpb, 0)[:M]).half().float()   # rounded, then + R
+        close(out, lin + res.float(), 2e-2, 5e-3, "256x160 dense %d %d %d" % (M, N, K))
+        assert lib.load().mc_gemm_last_kernel() == 56
+        assert torch.equal(out, ops.gemm(a, w, bias=bias, residual=res, alpha=0.5, rows_per_batch=rpb, cfg=11))
+    M, K, D = (300, 128, 80) if not big(dev) else (3000, 640, 640)
+    a = rnd((M, K), dev, 1)
+    wg = rnd((2 * D, K), dev, 8, 0.1)
+    bg = torch.randn(1, 2 * D, generator=torch.Generator().manual_seed(9)).to(dev)
+    y = a.float() @ wg.float().t() + bg
+    og = ops.gemm(a, ops.interleave_geglu(wg), bias=ops.interleave_geglu(bg.t()).t().contiguous(), geglu=True, cfg=9)
+    close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "256x160 geglu")
+    assert torch.equal(og, ops.gemm(a, ops.interleave_geglu(wg), bias=ops.interleave_geglu(bg.t()).t().contiguous(), geglu=True, cfg=11))
