@@ -19,7 +19,7 @@ int gn_partial_launch(const void* a, int lda, int ctot, int frames, int hw, floa
 using namespace mc;
 
 #ifndef MC_GEMM5_2WG_DEFAULT
-#define MC_GEMM5_2WG_DEFAULT 0     // measured choice of the product library (profiles/r04_gemm5_2wg.md)
+#define MC_GEMM5_2WG_DEFAULT -1    // measured choice of the product library (profiles/r04_gemm5_2wg.md): by `share`
 #endif
 
 extern "C" int mc_gn_nchunk(int hw);   // norm.hip
@@ -97,7 +97,11 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     // 256 x 160 tiles, 4 waves, TWO workgroups per CU (gemm5.hip, round 4).  G5_2WG: 0 = never, 1 = dense launches of about
     // one wave of 256 x 320 tiles, 2 = every dense launch with K <= 1280, 3 = every dense launch, 4 = wide short-K launches
     // (tools build: MC_GEMM5_2WG)
-    static const int two_wg = MC_ENV_INT("MC_GEMM5_2WG", MC_GEMM5_2WG_DEFAULT);
+    // Measured inside the step loop (profiles/r04_gemm5_2wg.md): ONE video in flight +1.0 ... +2.8 % (rule 4 / rule 3), THREE
+    // in flight -0.3 ... -2 % (the other streams already fill the prologue / epilogue gaps, and the geometry moves 1.44x the
+    // operand bytes per MFMA) - so the default (-1) takes rule 4 only when the caller keeps a single launch sequence in flight
+    static const int two_wg_env = MC_ENV_INT("MC_GEMM5_2WG", MC_GEMM5_2WG_DEFAULT);
+    const int two_wg = two_wg_env >= 0 ? two_wg_env : (share == 0 ? 4 : 0);
     if (big_cfg == 1 && automatic && !no_g5 && two_wg && mode == DENSE && N % 160 == 0) {
         const long b1 = (long)((M + 255) / 256) * (N / 320);
         // 4 = the shapes that gained inside the step loop (profiles/r04_gemm5_2wg.md): wide outputs (>= 12 column tiles of
