@@ -1,0 +1,28 @@
+#!/bin/bash
+# Round-4 record: the -m gpu suite, the driver's bench command, rocprofv3 kernel-trace stats of (a) the default command (hipGraph
+# replay, three videos in flight) and (b) one video at a time on the eager launch sequence, PMC HBM-traffic passes per shape,
+# SQ MFMA-busy passes, the other BASELINE configs.  Everything under gpurun_out/ (copied into profiles/ by hand).
+cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
+export TMPDIR=/tmp
+T=${1:-r04}
+mkdir -p gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/pmc_${T}
+timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/${T}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/${T}_pytest_gpu.log
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_final.log 2> gpurun_out/${T}_bench_final.err
+echo "driver-like bench rc=$?"; grep '^{' gpurun_out/${T}_bench_final.log | tail -n 1 > gpurun_out/${T}_bench_final_line.json; cut -c1-900 gpurun_out/${T}_bench_final_line.json; echo
+cp gpurun_out/r04_bench_detail.json gpurun_out/${T}_bench_final_detail.json
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_a -- python bench.py --no-cpu-baseline --no-vae --no-detail --steps 3 > gpurun_out/prof_${T}_a/bench.json 2> gpurun_out/prof_${T}_a/bench.err
+echo "trace a rc=$?"
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_b -- python bench.py --no-cpu-baseline --no-vae --no-detail --no-graphs --inflight 1 --steps 2 > gpurun_out/prof_${T}_b/bench.json 2> gpurun_out/prof_${T}_b/bench.err
+echo "trace b rc=$?"
+find gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b -name "*kernel_trace.csv" -delete
+python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/${T}_kernel_stats.md "round-4" || echo "kernel_stats_md failed"
+for c in FETCH_SIZE WRITE_SIZE; do
+  timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${T}/$c -- python tools/pmc_traffic.py run gpurun_out/pmc_${T} > gpurun_out/pmc_${T}/$c.log 2>&1; echo "pmc $c rc=$?"
+done
+python tools/pmc_traffic.py table gpurun_out/pmc_${T} > gpurun_out/${T}_hbm_traffic_per_shape.json 2> gpurun_out/${T}_pmc_hbm_traffic.md || echo "pmc table failed"
+tail -n 22 gpurun_out/${T}_pmc_hbm_traffic.md
+timeout 600 python bench.py --no-cpu-baseline --no-vae --no-detail --frames 16 --size 256 --ddim-steps 10 --guided-steps 5 --guidance-scale 0.3 --steps 16 --warmup 8 --inflight 8 > gpurun_out/${T}_bench_cfg1.json 2> gpurun_out/${T}_bench_cfg1.err
+timeout 600 python bench.py --no-cpu-baseline --no-vae --no-detail --sparsectrl --guided-steps 12 --guidance-scale 0.3 --steps 6 --warmup 3 > gpurun_out/${T}_bench_cfg4.json 2> gpurun_out/${T}_bench_cfg4.err
+timeout 900 python bench.py --no-cpu-baseline --no-vae --no-detail --frames 32 --size 768 --ddim-steps 50 --guided-steps 30 --steps 2 --warmup 2 --inflight 2 > gpurun_out/${T}_bench_cfg5.json 2> gpurun_out/${T}_bench_cfg5.err
+for c in 1 4 5; do python -c "
+import json; d=json.loads([l for l in open('gpurun_out/${T}_bench_cfg$c.json') if l.startswith('{')][-1]); print('cfg$c', d['value'], d['config']['workload'][:60], d.get('peak_reserved_gib'))" || tail -n 3 gpurun_out/${T}_bench_cfg$c.err; done

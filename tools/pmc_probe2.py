@@ -1,0 +1,37 @@
+"""Small workload for SQ-counter passes (rocprofv3 --pmc): the tiled GEMM / conv kernels (gemm3 and gemm5 on the same
+shapes) and the level-0 spatial attention, two launches each.  Prints the launch order."""
+import sys
+import torch
+sys.path.insert(0, ".")
+dev = torch.device("cuda:0")
+from motionclone_amd import ops  # noqa: E402
+
+
+def r(*s, sc=1.0):
+    return (torch.randn(*s, device=dev) * sc).half()
+
+
+what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
+if what == "gemm":
+    F = 32
+    x1, wq1, wo1, r1 = r(32768, 640), r(1920, 640, sc=0.02), r(640, 640, sc=0.02), r(32768, 640)
+    xc, wc = r(F * 1024, 1280), r(640, 9 * 1280, sc=0.02)
+    torch.cuda.synchronize()
+    for cfg in (1, 11, 12):
+        for _ in range(2):
+            ops.gemm(x1, wq1, cfg=cfg)                       # qkv level 1: M=32768 N=1920 K=640
+            ops.gemm(x1, wo1, residual=r1, cfg=cfg)          # to_out level 1 + R: one wave of tiles, K=640
+            ops.gemm(xc, wc, mode=ops.CONV_S1, geom=(32, 32, 32, 32), m_out=F * 1024, cfg=cfg)   # conv 1280->640, K=11520
+    print("order: for cfg in (1 = gemm3, 11 = gemm5, 12 = gemm5 no stagger): 2 x [qkv_l1, to_out_l1+R, conv_l1 K=11520]")
+else:
+    Fr, N, d = 16, 4096, 40
+    C = 8 * d
+    qkv = r(Fr * N, 3 * C, sc=0.5)
+    q, k, v = qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:]
+    for _ in range(2):
+        o, lse = ops.attn_fwd(q, k, v, N, N, 8, d, Fr)
+    do = r(Fr * N, C)
+    for _ in range(2):
+        ops.attn_bwd(q, k, v, o, do, lse, N, N, 8, d, Fr)
+    print("order: 2 x attn_fwd level 0 (16 f x 8 heads x 4096^2, d = 40), 2 x attn_bwd (dq, dkdv)")
+torch.cuda.synchronize()
