@@ -291,6 +291,9 @@ def main():
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
     ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r04_bench_detail.json")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
+    ap.add_argument("--batch", type=int, default=1, help="videos batched into ONE launch sequence per lane (latents [V, ...], text "
+                    "[u_1 .. u_V | c_1 .. c_V]: the same kernels on V times the rows); --inflight lanes x --batch videos are in "
+                    "flight together.  --steps must be a multiple of it")
     ap.add_argument("--inflight", type=int, default=3, help="independent videos processed concurrently per GPU (own HIP stream, "
                     "own sampler / graphs each).  At config 2: 2 in flight +8-10 %% videos/min over one (kernel tails and the "
                     "small 16x16 / 8x8-level kernels of one video are filled by the others), 3 in flight another +2.6 %%, 4 lose; "
@@ -358,7 +361,10 @@ def main():
     # sequence of one video leaves CUs idle in kernel tails and in the small 16x16 / 8x8-level kernels, which a second video
     # fills (measured +8-10 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).  Results are
     # bit-identical to the one-at-a-time run since the library is built without packed-fp32 VALU code (csrc/temporal.hip).
-    NF = max(1, min(args.inflight, args.steps))
+    VB = max(1, args.batch)
+    if args.steps % VB or (args.sparsectrl and VB > 1):
+        raise SystemExit("bench.py: --steps must be a multiple of --batch (and --batch 1 with --sparsectrl)")
+    NF = max(1, min(args.inflight, args.steps // VB))
     ops.set_gemm_share(args.gemm_lanes or NF)      # every launch of this process, timed region and probe alike (tile / split-K choice only)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     smps = [smp] + [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
@@ -367,14 +373,15 @@ def main():
     if use_graphs:
         for sm in smps:
             sm.enable_graphs()
-    # every lane of the in-flight set works on its own example (different seeds = different latents / noise)
-    lane_inputs = [(lat, text, vid, noise)] + [synth_inputs(dev, args.frames, args.size, args.size, seeds[(rank + 1 + k) % len(seeds)] + 7 * (k + 1))
-                                                for k in range(NF - 1)]
+    # every video of the in-flight set is its own example (different seeds = different latents / noise); a lane's job is one
+    # video, or a list of --batch videos that go through one launch sequence
+    all_inputs = [(lat, text, vid, noise)] + [synth_inputs(dev, args.frames, args.size, args.size, seeds[(rank + 1 + k) % len(seeds)] + 7 * (k + 1))
+                                               for k in range(NF * VB - 1)]
+    lane_inputs = [all_inputs[k] if VB == 1 else all_inputs[k * VB:(k + 1) * VB] for k in range(NF)]
 
     def run_videos(nvideos, step_events=None):
-        """nvideos videos, NF at a time (motionclone_amd.sampler.sample_interleaved)"""
+        """nvideos videos, NF lanes x VB videos at a time (motionclone_amd.sampler.sample_interleaved)"""
         last = None
-        done = 0
         pending = {}
 
         def on_step(k, i, enter):
@@ -387,14 +394,13 @@ def main():
             else:
                 step_events.append((i < G_STEPS, pending.pop(k), ev))
 
-        for k_act in plan_rounds(nvideos, NF):
+        for k_act in plan_rounds(nvideos // VB, NF):
             xs = sample_interleaved(smps[:k_act], lane_inputs[:k_act], streams[:k_act], add_noise_step=400, ctrl=ctrl,
                                     on_step=on_step)
             last = xs[0]
-            done += k_act
         return last
 
-    warm_videos = max(NF, args.warmup)     # every lane's first pass captures its graphs / fills its allocator pool: never timed
+    warm_videos = max(NF * VB, (args.warmup + VB - 1) // VB * VB)     # every lane's first pass captures its graphs / fills its allocator pool: never timed
     run_videos(warm_videos)
     torch.cuda.synchronize()
     # what the warm-up's eager passes left cached in the ordinary pool is of no use to the replays (they live in the lanes'
@@ -428,12 +434,16 @@ def main():
     if rank == 0:
         sme = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                                  num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng)
-        out_e = one_video(sme, lat, text, vid, noise, ctrl=ctrl)      # untimed eager warm-up
+        def eager_lane0():     # lane 0's job (one video, or its --batch videos as one launch sequence) without graphs
+            if VB == 1:
+                return one_video(sme, lat, text, vid, noise, ctrl=ctrl)
+            return sample_interleaved([sme], [lane_inputs[0]], None, add_noise_step=400, ctrl=ctrl)[0]
+        out_e = eager_lane0()      # untimed eager warm-up
         torch.cuda.synchronize()
         te0 = time.perf_counter()
-        out_e = one_video(sme, lat, text, vid, noise, ctrl=ctrl)
+        out_e = eager_lane0()
         torch.cuda.synchronize()
-        te = time.perf_counter() - te0
+        te = (time.perf_counter() - te0) / VB
         # the probe video runs with the tile / split-K choice of ONE video in flight (its regime), not the timed region's
         ops.set_gemm_share(1)
         one_video(sme, lat, text, vid, noise, ctrl=ctrl)              # the single-lane choice may touch new kernels: warm
@@ -501,7 +511,7 @@ def main():
             "value": videos / (elapsed / 60.0), "unit": "videos/min", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": "BASELINE config %s: %d frames, %dx%d, UNet%s only (extraction + %d guided + %d plain "
+            "config": {"videos_batched_per_lane": VB, "workload": "BASELINE config %s: %d frames, %dx%d, UNet%s only (extraction + %d guided + %d plain "
                                    "DDIM steps), schedule (%d,%d,%g)"
                                    % ("4 (i2v_rgb + SparseCtrl)" if args.sparsectrl else
                                       {(16, 512): "2 (t2v_object-style)", (32, 768): "5 (long clip)",

@@ -144,7 +144,9 @@ class Tape:
         self.fns = []
         self.grads = {}
         self.keep = []
-        self.grad_batch = grad_batch   # differentiate only this batch element of a B > 1 forward (None: all)
+        # differentiate only these batch elements of a B > 1 forward: an index b, or a range (b0, b1) = elements b0 .. b1 - 1
+        # (the conditional halves of several videos batched as [u_1 .. u_V | c_1 .. c_V]); None: all
+        self.grad_batch = grad_batch
         self.grad_scale = 1.0          # the gradients on this tape are carried at this multiple of their value
 
     def add(self, fn):
@@ -235,13 +237,24 @@ class UNet3DEngine:
 
     # ---- batch slicing for the backward ------------------------------------------------------------------
     @staticmethod
+    def _brange(geo, b):
+        """grad_batch -> (b0, b1): None = every batch element, an int = that one, a pair = the range"""
+        if b is None:
+            return 0, geo.B
+        if isinstance(b, (tuple, list)):
+            return int(b[0]), int(b[1])
+        return int(b), int(b) + 1
+
+    @staticmethod
     def _bslice(geo, b):
-        """The forward may run B = 2 (uncond | cond) while only batch element `b` is differentiated (the reference
-        runs them as two B = 1 calls, motionclone_functions.py:216-223 - per-sample results are identical).  Returns
-        the B = 1 geometry and a function that cuts batch b out of any saved per-token / per-frame / per-batch tensor;
-        token order is batch-major, so every slice is a contiguous row range (a view)."""
+        """The forward may run B = 2 (uncond | cond) - or B = 2 V for V videos batched as [u_1 .. u_V | c_1 .. c_V] - while only
+        the batch elements `b` (an index or a range (b0, b1)) are differentiated (the reference runs them as separate B = 1
+        calls, motionclone_functions.py:216-223 - per-sample results are identical).  Returns the geometry of the differentiated
+        part and a function that cuts it out of any saved per-token / per-frame / per-batch tensor; token order is batch-major,
+        so every slice is a contiguous row range (a view)."""
         if b is None:
             return geo, (lambda t: t)
+        b0, b1 = UNet3DEngine._brange(geo, b)
         T1 = geo.T // geo.B
 
         def cut(t):
@@ -249,12 +262,12 @@ class UNet3DEngine:
                 return None
             n = t.shape[0]
             if n == geo.T:
-                return t[b * T1:(b + 1) * T1]
+                return t[b0 * T1:b1 * T1]
             if n == geo.frames:
-                return t[b * geo.F:(b + 1) * geo.F]
+                return t[b0 * geo.F:b1 * geo.F]
             per = n // geo.B          # per-batch rows (text keys/values, time bias)
-            return t[b * per:(b + 1) * per]
-        return Geo(1, geo.F, geo.H, geo.W), cut
+            return t[b0 * per:b1 * per]
+        return Geo(b1 - b0, geo.F, geo.H, geo.W), cut
 
     def _gn_gemm(self, x, gname, bname, wname, wbias, fr, hw):
         """GroupNorm(32, eps 1e-6, no activation) + the 1x1 proj_in (attention.py:105-117, motion_module.py:145-151) ->
@@ -296,7 +309,8 @@ class UNet3DEngine:
             n, _ = ops.layernorm_fwd(h, g, b, save_stats=False)
             return ops.gemm(n, w.geglu_lin(wname), bias=w.geglu_vec(biasname), geglu=True), None, None
         T1 = T // geo.B
-        lo, hi = (0, T) if (gb is None or geo.B == 1) else (gb * T1, (gb + 1) * T1)
+        b0, b1 = self._brange(geo, gb)
+        lo, hi = b0 * T1, b1 * T1
         W1, b1 = w.lin(wname), w.vec(biasname).unsqueeze(0)
         gg = ops.empty((T, W1.shape[0] // 2), h)
         ls = ops.empty((T, 2), h, torch.float32)       # only rows lo .. hi (the differentiated batch element) are read later
@@ -578,7 +592,8 @@ class UNet3DEngine:
                 dout = tape.take(x0)
                 if dout is None:
                     return
-                nb = 1 if tape.grad_batch is not None else B
+                b0, b1 = self._brange(geo, tape.grad_batch)
+                nb = b1 - b0
                 dxin = ops.gemm(dout, w.conv_dgrad("conv_in.weight", pad_cin=CIN_PAD), mode=CONV_S1,
                                 geom=(H, W, H, W), m_out=nb * F * H * W)
                 tape.latent_grad = ops.cl_to_latent(dxin, nb, CL, F, H, W, scale=1.0 / tape.grad_scale, f32=True)
@@ -663,7 +678,15 @@ class UNet3DEngine:
         return rep
 
     def prepare_representation(self, rep):
-        """reference .pt dict {name: [values [BN, heads, F, 1], indices uint8]} -> device tensors for the kernels"""
+        """reference .pt dict {name: [values [BN, heads, F, 1], indices uint8]} -> device tensors for the kernels.
+        A LIST of such dicts (V videos batched in one forward, guided_eps_and_grad) is concatenated along the (b, pixel) axis
+        in video order - the order of the conditional halves [c_1 .. c_V] in the batch."""
+        if isinstance(rep, (list, tuple)):
+            parts = [self.prepare_representation(r) for r in rep]
+            if len(parts) == 1:
+                return parts[0]
+            return {name: (torch.cat([p[name][0] for p in parts], 0).contiguous(), torch.cat([p[name][1] for p in parts], 0).contiguous())
+                    for name in parts[0]}
         out = {}
         for name, (val, idx) in rep.items():
             out[name] = (idx.to(self.dev, torch.uint8).contiguous(), val.to(self.dev, torch.float32).contiguous())
@@ -676,23 +699,32 @@ class UNet3DEngine:
         (motionclone_functions.py:221-236).  With `text_uncond` the un-guided eps_u of :216-219 is produced by the same
         launch sequence: one B = 2 forward over [uncond | cond] whose tape differentiates batch element 1 only
         (residuals, if any, are then the B = 2 SparseCtrl outputs).
-        Returns (eps_c tokens, grad fp32 [1,4,F,H,W], loss or None[, eps_u tokens])."""
+
+        V > 1 videos at once (latents [V, 4, F, H, W], text_* [V, n, dim], `rep_dev` = prepare_representation of the list of
+        their representations; needs text_uncond): ONE B = 2 V forward over [u_1 .. u_V | c_1 .. c_V], the tape differentiates
+        the conditional halves; every video's loss is its own mean (the seed coefficient uses the per-video element count), so
+        each video gets exactly the gradient of its separate call.
+        Returns (eps_c tokens, grad fp32 [V,4,F,H,W], loss (summed over the videos) or None[, eps_u tokens])."""
         batched = text_uncond is not None
-        tape = Tape(grad_batch=1 if batched else None)
+        V = latents.shape[0]
+        if V > 1 and not batched:
+            raise ValueError("several videos per call need text_uncond (one [u_1 .. u_V | c_1 .. c_V] forward)")
+        tape = Tape(grad_batch=(V, 2 * V) if batched else None)
         # The loss is a MEAN over the attention maps (F.mse_loss, :229), so the gradient per element shrinks with the size of
         # the problem: 4e-5 at the latent for config 2, 6e-6 for config 5 (32 f x 96^2), where `grad_scale` = 1024 left the deep
         # layers' fp16 gradient activations in the subnormal range (gradient 1.8e-2 from the fp32 oracle against 7e-3 at every
         # smaller size, tests/test_fullsize_parity.py).  The scale therefore follows the map size in powers of two from the
         # validated point (config 2: 32768 elements per hooked attention): exact to undo, same dynamic range at every size.
-        numel_max = max((idx.numel() for idx, _ in rep_dev.values()), default=1)
+        numel_max = max((idx.numel() // V for idx, _ in rep_dev.values()), default=1)
         tape.grad_scale = self.grad_scale * float(2 ** max(0, round(math.log2(max(1.0, numel_max / 32768.0)))))
         seeds = {}
         for name, (idx, val) in rep_dev.items():
-            numel = idx.numel()
+            numel = idx.numel() // V              # per video: F.mse_loss averages over ONE video's map
             seeds[name] = (idx, val, tape.grad_scale * float(weight) * 2.0 / numel)
         record = {}
         if batched:
-            eps2 = self.forward(latents.expand(2, -1, -1, -1, -1), t, torch.cat([text_uncond, text_cond], 0), tape=tape,
+            lat2 = latents.expand(2, -1, -1, -1, -1) if V == 1 else torch.cat([latents, latents], 0)
+            eps2 = self.forward(lat2, t, torch.cat([text_uncond, text_cond], 0), tape=tape,
                                 record=record, seeds=seeds, down_residuals=down_residuals, mid_residual=mid_residual)
             T1 = eps2.shape[0] // 2
             eps_u, eps_c = eps2[:T1], eps2[T1:]
@@ -707,7 +739,7 @@ class UNet3DEngine:
                 C, g = r["C"], r["geo"]
                 lm = ops.tattn_loss(r["qkv"][:, :C], r["qkv"][:, C:2 * C], idx, val, g.B, g.F, g.hw, r["heads"], r["d"])
                 total = lm if total is None else total + lm
-            loss = total * float(weight)
+            loss = total * (float(weight) * V)   # tattn_loss is the mean over all V maps; the sum of the V means is V x that
         tape.latent_grad = None
         tape.run()
         grad = tape.latent_grad

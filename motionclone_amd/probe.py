@@ -140,11 +140,29 @@ class LaunchProbe:
             probe.records.append((fam, e0, e1, fl, nb, shape))
             return rc
         lib.call = call
+        # entry points that may answer "unsupported" (lib.try_call: mc_norm_gemm_f16) are bracketed the same way; a refused
+        # call launched nothing and leaves no record
+        self._orig_try = lib.try_call
+
+        def try_call(name, *args):
+            if not probe.enabled:
+                return probe._orig_try(name, *args)
+            n0 = len(probe.records)
+            saved, probe._orig = probe._orig, probe._orig_try
+            try:
+                ok = call(name, *args)
+            finally:
+                probe._orig = saved
+            if not ok:
+                del probe.records[n0:]
+            return ok
+        lib.try_call = try_call
         return self
 
     def uninstall(self):
         if self._orig is not None:
             lib.call = self._orig
+            lib.try_call = self._orig_try
             self._orig = None
 
     def reset(self):

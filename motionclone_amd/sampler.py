@@ -186,20 +186,38 @@ class MotionCloneSampler:
 
     @ops.scoped
     def _step_eager(self, latents, i, text, rep_dev, aux=None, ctrl=None, sigma=0.0):
+        """latents [V, 4, F, H, W]; text [2 V, n, dim] ordered [u_1 .. u_V | c_1 .. c_V] (V = 1: [uncond, cond], the reference's
+        layout); rep_dev: engine.prepare_representation of the V representations (a list for V > 1).  V > 1 = V independent
+        videos through ONE launch sequence (same kernels, V times the rows): each video's arithmetic is its own - no
+        reduction crosses the batch - but the GEMM tile / split-K choice follows the larger row count, so results agree
+        with the one-video path to fp16 rounding, not bit for bit."""
         from .engine import split_residuals
         eng = self.engine
+        V = latents.shape[0]
+        if text.shape[0] != 2 * V:
+            raise ValueError("text must hold [uncond x V | cond x V] embeddings: %s for %d videos" % (tuple(text.shape), V))
+        if V > 1 and (ctrl is not None or not self.batch_guided):
+            raise NotImplementedError("several videos per step: not with SparseCtrl / batch_guided=False")
         t, a_t, a_prev = self._alphas(i)
         down = mid = None
         if ctrl is not None:
             shape2 = (2,) + tuple(latents.shape[1:])
             down, mid = self.controlnet.forward(shape2, t, text, ctrl["cond"], ctrl["mask"], ctrl.get("scale", 1.0))
+
+        def update(eps_c, eps_u, grad, coef):
+            if V == 1:
+                return ops.cfg_ddim_step(eps_c, eps_u, latents, grad, self.cfg_scale, a_t, a_prev, coef, sigma=sigma)
+            T1 = eps_c.shape[0] // V           # the fused CFG + DDIM update works on one video's rows at a time
+            return torch.cat([ops.cfg_ddim_step(eps_c[v * T1:(v + 1) * T1], eps_u[v * T1:(v + 1) * T1], latents[v:v + 1],
+                                                None if grad is None else grad[v:v + 1], self.cfg_scale, a_t, a_prev, coef,
+                                                sigma=sigma) for v in range(V)], 0)
         if i < self.G:
             w = self.weight * self.guidance_factor(i)
             if self.batch_guided:
-                # eps_u and eps_c from ONE B = 2 forward; only the conditional half is differentiated
-                eps_c, grad, loss, eps_u = eng.guided_eps_and_grad(latents, t, text[1:2], rep_dev, w,
+                # eps_u and eps_c from ONE B = 2 V forward; only the conditional halves are differentiated
+                eps_c, grad, loss, eps_u = eng.guided_eps_and_grad(latents, t, text[V:], rep_dev, w,
                                                                    want_loss=aux is not None, down_residuals=down,
-                                                                   mid_residual=mid, text_uncond=text[0:1])
+                                                                   mid_residual=mid, text_uncond=text[:V])
             else:
                 du = mu = dc = mc = None
                 if down is not None:
@@ -211,12 +229,13 @@ class MotionCloneSampler:
             if aux is not None:
                 aux.update(eps_u=eps_u, eps_c=eps_c, grad=grad, loss=loss)
             coef = self.score_gs * (1.0 - a_t) ** 0.5
-            return ops.cfg_ddim_step(eps_c, eps_u, latents, grad, self.cfg_scale, a_t, a_prev, coef, sigma=sigma)
-        eps2 = eng.forward(latents.expand(2, -1, -1, -1, -1), t, text, down_residuals=down, mid_residual=mid)
+            return update(eps_c, eps_u, grad, coef)
+        lat2 = latents.expand(2, -1, -1, -1, -1) if V == 1 else torch.cat([latents, latents], 0)
+        eps2 = eng.forward(lat2, t, text, down_residuals=down, mid_residual=mid)
         T1 = eps2.shape[0] // 2
         if aux is not None:
             aux.update(eps_u=eps2[:T1], eps_c=eps2[T1:])
-        return ops.cfg_ddim_step(eps2[T1:], eps2[:T1], latents, None, self.cfg_scale, a_t, a_prev, 0.0, sigma=sigma)
+        return update(eps2[T1:], eps2[:T1], None, 0.0)
 
     def sample(self, latents, text, rep, progress=None, ctrl=None):
         rep_dev = self.engine.prepare_representation(rep)
@@ -230,7 +249,8 @@ class MotionCloneSampler:
 def sample_interleaved(samplers, jobs, streams=None, add_noise_step=400, ctrl=None, on_step=None):
     """Several independent videos in flight on one GPU (examples are the unit of parallelism).
 
-    `jobs[k] = (latents, text [2,77,768], reference_video_latents, extraction_noise)` runs on `samplers[k]` / `streams[k]`
+    `jobs[k] = (latents, text [2,77,768], reference_video_latents, extraction_noise)` - or a LIST of such tuples: V videos
+    batched into one launch sequence on that lane (the result is then [V, 4, F, H, W]) - runs on `samplers[k]` / `streams[k]`
     (one sampler per lane: each owns its hipGraphs and static buffers); step i of every job is issued before step i + 1
     of any, so the kernels of the lanes interleave on the device and fill each other's tails.  Results are bit-identical
     to running the jobs one after the other (tools/concurrency_check.py) under the same `ops.set_gemm_share` setting
@@ -247,21 +267,24 @@ def sample_interleaved(samplers, jobs, streams=None, add_noise_step=400, ctrl=No
     import contextlib
     lane = (lambda k: contextlib.nullcontext()) if streams is None else (lambda k: torch.cuda.stream(streams[k]))
     if streams is not None:
-        cur = torch.cuda.current_stream(jobs[0][0].device)
+        first = jobs[0][0] if isinstance(jobs[0], list) else jobs[0]
+        cur = torch.cuda.current_stream(first[0].device)
         for st in streams[:n]:
             st.wait_stream(cur)
-    xs, reps = [None] * n, [None] * n
-    for k, (lat, text, vid, noise) in enumerate(jobs):
+    xs, reps, texts = [None] * n, [None] * n, [None] * n
+    for k, job in enumerate(jobs):
+        vids = job if isinstance(job, list) else [job]       # a LIST of videos on one lane = one batched launch sequence
         with lane(k):
-            rep = samplers[k].extract(vid, noise, text[0:1], add_noise_step=add_noise_step, ctrl=ctrl)
-            reps[k] = samplers[k].engine.prepare_representation(rep)
-            xs[k] = lat
+            rr = [samplers[k].extract(vid, noise, text[0:1], add_noise_step=add_noise_step, ctrl=ctrl) for (_, text, vid, noise) in vids]
+            reps[k] = samplers[k].engine.prepare_representation(rr if len(vids) > 1 else rr[0])
+            xs[k] = vids[0][0] if len(vids) == 1 else torch.cat([v[0] for v in vids], 0)
+            texts[k] = vids[0][1] if len(vids) == 1 else torch.cat([v[1][0:1] for v in vids] + [v[1][1:2] for v in vids], 0)
     for i in range(len(samplers[0].timesteps)):
         for k in range(n):
             with lane(k):
                 if on_step is not None:
                     on_step(k, i, True)
-                xs[k] = samplers[k].step(xs[k], i, jobs[k][1], reps[k], ctrl=ctrl)
+                xs[k] = samplers[k].step(xs[k], i, texts[k], reps[k], ctrl=ctrl)
                 if on_step is not None:
                     on_step(k, i, False)
     if streams is not None:

@@ -232,3 +232,54 @@ def test_step_with_eta_matches_the_scheduler_formula(backend, tiny):
     assert torch.equal(drawn, smp.step(lat, i, text, rep_dev, eta=0.6, variance_noise=z2))
     with pytest.raises(ValueError, match="Cannot pass both generator and variance_noise"):
         smp.step(lat, i, text, rep_dev, eta=0.6, variance_noise=z2, generator=torch.Generator(device=dev))
+
+
+def test_videos_batched_in_one_launch_sequence_match_their_separate_steps(backend, tiny):
+    """round 4: V independent videos through ONE launch sequence (latents [V, ...], text [u_1 .. u_V | c_1 .. c_V], the tape
+    differentiating the conditional halves): every video's guided step (eps, guidance gradient with ITS OWN loss mean),
+    plain step and the interleaved sampler loop agree with its separate V = 1 run and with the oracle"""
+    from motionclone_amd.sampler import sample_interleaved
+    dev = backend
+    cfg, sd = tiny
+    eng = UNet3DEngine(sd, cfg, dev)
+    N, Gs, gs = 3, 2, 0.3
+    smp = MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gs, **HP)
+    vids = []
+    for v in range(2):
+        g = torch.Generator().manual_seed(100 + v)
+        lat = torch.randn(1, 4, 4, 8, 8, generator=g).half().to(dev)
+        text = torch.randn(2, 7, cfg["cross_attention_dim"], generator=g).half().to(dev)
+        vid = (0.18215 * torch.randn(1, 4, 4, 8, 8, generator=g)).half().to(dev)
+        noise = torch.randn(1, 4, 4, 8, 8, generator=g).half().to(dev)
+        vids.append((lat, text, vid, noise))
+    reps = [smp.extract(vid, noise, text[0:1]) for (_, text, vid, noise) in vids]
+    rep_devs = [eng.prepare_representation(r) for r in reps]
+    rep_cat = eng.prepare_representation(reps)
+    lat2 = torch.cat([v[0] for v in vids], 0)
+    text2 = torch.cat([v[1][0:1] for v in vids] + [v[1][1:2] for v in vids], 0)
+    ts = G.uneven_timesteps(N, Gs, gs)
+    for i in (0, Gs):                      # one guided, one plain step
+        aux2 = {}
+        nxt2 = smp.step(lat2, i, text2, rep_cat, aux=aux2)
+        assert nxt2.shape == lat2.shape
+        for v, (lat, text, _, _) in enumerate(vids):
+            aux1 = {}
+            nxt1 = smp.step(lat, i, text, rep_devs[v], aux=aux1)
+            assert rel_err(nxt2[v:v + 1], nxt1) < 2e-3, (i, v, rel_err(nxt2[v:v + 1], nxt1))
+            if i < Gs:
+                assert rel_err(aux2["grad"][v:v + 1], aux1["grad"]) < 2e-2
+                rep_cpu = {k: [a.float().cpu(), b.cpu()] for k, (a, b) in reps[v].items()}
+                ref, ref_aux = G.guided_step(sd, cfg, lat.float().cpu(), i, ts, text.float().cpu(), rep_cpu, dict(HP, guidance_steps=Gs))
+                assert rel_err(nxt2[v:v + 1], ref) < 2e-2 and rel_err(aux2["grad"][v:v + 1], ref_aux["grad"]) < 5e-2
+        if i < Gs:   # the loss of the batch is the sum of the videos' own means
+            l1 = sum(float(smp.engine.guided_eps_and_grad(lat, int(ts[i]), text[1:2], rep_devs[v], 1.0, want_loss=True,
+                                                          text_uncond=text[0:1])[2]) for v, (lat, text, _, _) in enumerate(vids))
+            l2 = float(eng.guided_eps_and_grad(lat2, int(ts[i]), text2[2:], rep_cat, 1.0, want_loss=True, text_uncond=text2[:2])[2])
+            assert abs(l1 - l2) < 2e-3 * abs(l1), (l1, l2)
+    # the sampler loop: both videos as ONE batched lane vs one lane each
+    a = sample_interleaved([smp], [list(vids)])[0]
+    smp2 = MotionCloneSampler(eng, num_inference_steps=N, guidance_steps=Gs, guidance_scale=gs, **HP)
+    b = sample_interleaved([smp, smp2], vids)
+    assert a.shape[0] == 2
+    for v in range(2):
+        assert rel_err(a[v:v + 1], b[v]) < 5e-3, rel_err(a[v:v + 1], b[v])

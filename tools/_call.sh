@@ -1,5 +1,4 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-export MC_HIP_LIB=$PWD/tools/_build/libmotionclone_hip_tools.so
-for g in 0 4 0 4; do
-MC_GEMM5_2WG=$g timeout 400 python bench.py --steps 9 --warmup 3 --no-cpu-baseline --no-vae --no-detail > gpurun_out/r04_bench_2wgsel$g.log 2>&1; echo "2WG=$g $(grep '^{' gpurun_out/r04_bench_2wgsel$g.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["eager_one_video_at_a_time_videos_per_min"], d["roofline"]["kernel"], d["roofline"]["frac"])')"
+for cfg in "2 2" "1 2" "1 3" "2 3" "1 4"; do set -- $cfg
+timeout 500 python bench.py --steps 12 --warmup 3 --inflight $1 --batch $2 --no-cpu-baseline --no-vae --no-detail > gpurun_out/r04_bench_if$1_b$2.log 2>&1; echo "inflight=$1 batch=$2 $(grep '^{' gpurun_out/r04_bench_if$1_b$2.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["eager_one_video_at_a_time_videos_per_min"], d["identical_to_eager_path"], d["peak_reserved_gib"])' 2>&1 | tail -1)"; tail -2 gpurun_out/r04_bench_if$1_b$2.log | grep -i "error\|Traceback" 
 done

@@ -3,6 +3,7 @@
   workload:  rocprofv3 --pmc FETCH_SIZE  --output-format csv -d OUT/FETCH_SIZE -- python tools/pmc_traffic.py run OUT
              rocprofv3 --pmc WRITE_SIZE  --output-format csv -d OUT/WRITE_SIZE -- python tools/pmc_traffic.py run OUT
   table:     python tools/pmc_traffic.py table OUT > profiles/hbm_traffic_per_shape.json   (+ a markdown table on stderr)
+  PMC_LANES=3 in the environment of `run`: the tile choice of three videos in flight (default 1 = the roofline probe's regime)
 
 Separate passes, counters only (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots).  Units: KiB; on gfx950 FETCH_SIZE
 reports half of a wide coalesced read, so traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes.  The library chooses the kernel
@@ -32,6 +33,9 @@ def run(out):
     from motionclone_amd import lib, ops
     from motionclone_amd.probe import _gemm_name
     dev = torch.device("cuda:0")
+    # the tile choice depends on how many launch sequences the caller keeps in flight (ops.set_gemm_share): PMC_LANES = 1 is the
+    # regime of bench.py's roofline probe, 3 the timed region's
+    ops.set_gemm_share(int(os.environ.get("PMC_LANES", "1")))
 
     def r(*s, sc=1.0):
         return (torch.randn(*s, device=dev) * sc).half()
