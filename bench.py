@@ -289,6 +289,8 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--gemm-lanes", type=int, default=0, help="value handed to ops.set_gemm_share (0 = the number of videos in flight)")
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
+    ap.add_argument("--no-norm-fusion", action="store_true", help="A/B: LayerNorm / GroupNorm as separate launches in front of the "
+                    "K = 320 GEMMs (the round-3 launch sequence) instead of mc_norm_gemm_f16")
     ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r04_bench_detail.json")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     ap.add_argument("--batch", type=int, default=1, help="videos batched into ONE launch sequence per lane (latents [V, ...], text "
@@ -318,6 +320,8 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
     lib.load()  # fails loudly if the gfx950 library is missing
+    if args.no_norm_fusion:
+        ops.NORM_GEMM_MIN_ROWS = 1 << 62
 
     cfg = default_config()
     total = sum(int(torch.Size(s).numel()) for s in spec.param_shapes(cfg).values())
