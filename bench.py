@@ -252,6 +252,8 @@ def compact_line(res, detail_path, limit=4000):
         line["identical_to_eager_path"] = res["eager"]["identical_to_graph_path"]
     if res.get("hbm_footprint"):
         line["peak_reserved_gib"] = res["hbm_footprint"]["peak_reserved_gib"]
+    if "warmup_seconds" in res:
+        line["cold_start_seconds"] = res["warmup_seconds"]     # warm-up videos incl. the graph captures of every lane
     line["detail"] = detail_path
     out = json.dumps(line)
     if len(out) > limit:      # never let a long string cost the record: drop the prose first
@@ -405,8 +407,10 @@ def main():
         return last
 
     warm_videos = max(NF * VB, (args.warmup + VB - 1) // VB * VB)     # every lane's first pass captures its graphs / fills its allocator pool: never timed
+    t_warm0 = time.perf_counter()
     run_videos(warm_videos)
     torch.cuda.synchronize()
+    warm_seconds = time.perf_counter() - t_warm0      # cold start: lazy weight packing, one eager pass per kind of step, 30 captures per lane
     # what the warm-up's eager passes left cached in the ordinary pool is of no use to the replays (they live in the lanes'
     # graph pools): hand it back, and count the footprint of the timed region on its own
     torch.cuda.empty_cache()
@@ -544,7 +548,7 @@ def main():
             # SURVEY.md 8(f) rank 1, measured OUTSIDE the timed region (BASELINE's metric is the UNet loop): the VAE calls
             # around it - decode_latents of the sampled video and the encode of the reference video - on the same kernels
             "vae": vae_info,
-            "warmup_videos_run": warm_videos,
+            "warmup_videos_run": warm_videos, "warmup_seconds": warm_seconds,
             "graphs": graph_info,
             "eager": eager_info,
         }

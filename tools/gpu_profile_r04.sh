@@ -16,11 +16,21 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 echo "trace b rc=$?"
 find gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b -name "*kernel_trace.csv" -delete
 python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/${T}_kernel_stats.md "round-4" || echo "kernel_stats_md failed"
-for c in FETCH_SIZE WRITE_SIZE; do
-  timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${T}/$c -- python tools/pmc_traffic.py run gpurun_out/pmc_${T} > gpurun_out/pmc_${T}/$c.log 2>&1; echo "pmc $c rc=$?"
+# same box, same command: the norms as separate launches (the round-3 launch sequence) vs inside the K = 320 GEMMs
+for v in off on off on; do
+  f=""; [ $v = off ] && f="--no-norm-fusion"
+  timeout 400 python bench.py --steps 9 --warmup 3 --no-cpu-baseline --no-vae --no-detail $f > gpurun_out/${T}_bench_fusion_$v.log 2>&1
+  echo "norm fusion $v: $(grep '^{' gpurun_out/${T}_bench_fusion_$v.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["eager_one_video_at_a_time_videos_per_min"])')" | tee -a gpurun_out/${T}_bench_norm_fusion_ab.txt
 done
-python tools/pmc_traffic.py table gpurun_out/pmc_${T} > gpurun_out/${T}_hbm_traffic_per_shape.json 2> gpurun_out/${T}_pmc_hbm_traffic.md || echo "pmc table failed"
-tail -n 22 gpurun_out/${T}_pmc_hbm_traffic.md
+# HBM traffic per shape in both tile-choice regimes: one launch sequence in flight (the roofline probe) and three (the timed region)
+for L in 1 3; do
+  mkdir -p gpurun_out/pmc_${T}_l$L
+  for c in FETCH_SIZE WRITE_SIZE; do
+    PMC_LANES=$L timeout 300 rocprofv3 --pmc $c --output-format csv -d gpurun_out/pmc_${T}_l$L/$c -- python tools/pmc_traffic.py run gpurun_out/pmc_${T}_l$L > gpurun_out/pmc_${T}_l$L/$c.log 2>&1; echo "pmc lanes=$L $c rc=$?"
+  done
+  python tools/pmc_traffic.py table gpurun_out/pmc_${T}_l$L > gpurun_out/${T}_hbm_traffic_per_shape_l$L.json 2> gpurun_out/${T}_pmc_hbm_traffic_l$L.md || echo "pmc table failed"
+done
+tail -n 17 gpurun_out/${T}_pmc_hbm_traffic_l3.md
 timeout 600 python bench.py --no-cpu-baseline --no-vae --no-detail --frames 16 --size 256 --ddim-steps 10 --guided-steps 5 --guidance-scale 0.3 --steps 16 --warmup 8 --inflight 8 > gpurun_out/${T}_bench_cfg1.json 2> gpurun_out/${T}_bench_cfg1.err
 timeout 600 python bench.py --no-cpu-baseline --no-vae --no-detail --sparsectrl --guided-steps 12 --guidance-scale 0.3 --steps 6 --warmup 3 > gpurun_out/${T}_bench_cfg4.json 2> gpurun_out/${T}_bench_cfg4.err
 timeout 900 python bench.py --no-cpu-baseline --no-vae --no-detail --frames 32 --size 768 --ddim-steps 50 --guided-steps 30 --steps 2 --warmup 2 --inflight 2 > gpurun_out/${T}_bench_cfg5.json 2> gpurun_out/${T}_bench_cfg5.err
