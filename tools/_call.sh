@@ -1,4 +1,7 @@
-cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export TMPDIR=/tmp
-for cfg in "2 2" "1 2" "1 3" "2 3" "1 4"; do set -- $cfg
-timeout 500 python bench.py --steps 12 --warmup 3 --inflight $1 --batch $2 --no-cpu-baseline --no-vae --no-detail > gpurun_out/r04_bench_if$1_b$2.log 2>&1; echo "inflight=$1 batch=$2 $(grep '^{' gpurun_out/r04_bench_if$1_b$2.log | python -c 'import sys,json; d=json.loads(sys.stdin.read()); print(d["value"], d["eager_one_video_at_a_time_videos_per_min"], d["identical_to_eager_path"], d["peak_reserved_gib"])' 2>&1 | tail -1)"; tail -2 gpurun_out/r04_bench_if$1_b$2.log | grep -i "error\|Traceback" 
-done
+cd $GRAFT_REPO_ROOT; export TMPDIR=/tmp; mkdir -p gpurun_out
+rocm-smi --showclocks --showpower --csv 2>/dev/null | head -3
+export MC_HIP_LIB=$PWD/tools/_build/libmotionclone_hip_tools.so
+MC_GEMM5_2WG=0 bash tools/smi_power.sh r04_pw_3lanes_8wave --steps 9 --warmup 3 --no-cpu-baseline --no-vae --no-detail | tee -a gpurun_out/r04_power_clock.jsonl
+MC_GEMM5_2WG=3 bash tools/smi_power.sh r04_pw_3lanes_2wg --steps 9 --warmup 3 --no-cpu-baseline --no-vae --no-detail | tee -a gpurun_out/r04_power_clock.jsonl
+MC_GEMM5_2WG=0 bash tools/smi_power.sh r04_pw_1lane_8wave --steps 6 --warmup 1 --inflight 1 --no-graphs --no-cpu-baseline --no-vae --no-detail | tee -a gpurun_out/r04_power_clock.jsonl
+MC_GEMM5_2WG=3 bash tools/smi_power.sh r04_pw_1lane_2wg --steps 6 --warmup 1 --inflight 1 --no-graphs --no-cpu-baseline --no-vae --no-detail | tee -a gpurun_out/r04_power_clock.jsonl
