@@ -7,6 +7,7 @@ export TMPDIR=/tmp
 T=${1:-r04}
 mkdir -p gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/pmc_${T}
 timeout 1200 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/${T}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/${T}_pytest_gpu.log
+timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 2
 timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_final.log 2> gpurun_out/${T}_bench_final.err
 echo "driver-like bench rc=$?"; grep '^{' gpurun_out/${T}_bench_final.log | tail -n 1 > gpurun_out/${T}_bench_final_line.json; cut -c1-900 gpurun_out/${T}_bench_final_line.json; echo
 cp gpurun_out/r04_bench_detail.json gpurun_out/${T}_bench_final_detail.json
