@@ -54,7 +54,7 @@ na, ta, ma, tab_a = table(pa, va)
 nb, tb, mb, tab_b = table(pb, vb)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
-`tools/gpu_profile_r03_final.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
+`tools/gpu_profile_r04.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
 timed, and the four eager videos of the bench's probe pass).  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM>` (MODE 0 dense, 1
 conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU), `gemm4_kernel<20, GEGLU>` = K = 320 streaming kernel,
 `attn_*_ring_kernel<DT, rows/16 per wave>` = the LDS-DMA ring attention (DT 3: d = 40, 5: d = 80).
