@@ -55,8 +55,9 @@ nb, tb, mb, tab_b = table(pb, vb)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
 `tools/gpu_profile_r04.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
-timed, and the four eager videos of the bench's probe pass).  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM>` (MODE 0 dense, 1
-conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU), `gemm4_kernel<20, GEGLU>` = K = 320 streaming kernel,
+timed, and the four eager videos of the bench's probe pass).  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, ring stages>` (MODE 0 dense, 1
+conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU; 256, 160, 4, 3 = two workgroups per CU), `gemm4_kernel<20, GEGLU, NORM>` = K = 320 streaming
+kernel (NORM 1 = LayerNorm, 2 = GroupNorm applied to the rows in registers),
 `attn_*_ring_kernel<DT, rows/16 per wave>` = the LDS-DMA ring attention (DT 3: d = 40, 5: d = 80).
 
 ## (a) DEFAULT command `python bench.py --no-cpu-baseline --no-vae --steps 3`: hipGraph replay, three videos in flight (kernel durations are measured while kernels of the other two videos share the CUs)
