@@ -12,7 +12,18 @@ def r(*s, sc=1.0):
 
 
 what = sys.argv[1] if len(sys.argv) > 1 else "gemm"
-if what == "gemm":
+if what == "twowg":
+    # round 4: the short-K dense layers on the 8-wave 256 x 320 tiles (cfg 11) and on 256 x 160 tiles, two workgroups per CU (cfg 9)
+    x1, wo1, r1 = r(32768, 640), r(640, 640, sc=0.02), r(32768, 640)
+    wq1, wg1 = r(1920, 640, sc=0.02), r(5120, 640, sc=0.02)
+    torch.cuda.synchronize()
+    for cfg in (11, 9):
+        for _ in range(2):
+            ops.gemm(x1, wo1, residual=r1, cfg=cfg)          # to_out level 1 + R: one wave of 256 x 320 tiles, K = 640
+            ops.gemm(x1, wq1, cfg=cfg)                       # qkv level 1
+            ops.gemm(x1, wg1, geglu=True, cfg=cfg)           # FeedForward level 1, fused GEGLU
+    print("order: for cfg in (11 = 8 waves, 9 = two workgroups per CU): 2 x [to_out_l1+R, qkv_l1, ff1_l1 geglu]")
+elif what == "gemm":
     F = 32
     x1, wq1, wo1, r1 = r(32768, 640), r(1920, 640, sc=0.02), r(640, 640, sc=0.02), r(32768, 640)
     xc, wc = r(F * 1024, 1280), r(640, 9 * 1280, sc=0.02)
