@@ -97,3 +97,27 @@ def test_a_mismatched_launcher_is_an_error_not_an_assert(bench, monkeypatch):
     with pytest.raises(SystemExit) as e:
         bench.main()
     assert "WORLD_SIZE=4" in str(e.value)
+
+
+def test_rounds_of_videos_in_flight(bench):
+    """--steps videos in rounds of up to --inflight lanes, never leaving a single video for the last round when avoidable"""
+    assert bench.plan_rounds(20, 3) == [3, 3, 3, 3, 3, 3, 2]
+    assert bench.plan_rounds(4, 3) == [2, 2] and bench.plan_rounds(7, 3) == [3, 2, 2] and bench.plan_rounds(5, 3) == [3, 2]
+    assert bench.plan_rounds(1, 3) == [1] and bench.plan_rounds(6, 2) == [2, 2, 2] and bench.plan_rounds(0, 3) == []
+    for n in range(1, 40):
+        for lanes in (1, 2, 3, 4):
+            r = bench.plan_rounds(n, lanes)
+            assert sum(r) == n and max(r) <= lanes and (1 not in r or n == 1 or lanes <= 2 and n % lanes == 1 or lanes == 1)
+
+
+def test_probe_prices_the_fused_norm_gemm_by_its_own_arguments():
+    """the roofline probe takes flop / bytes from the C-ABI arguments of the call it brackets: mc_norm_gemm_f16"""
+    from motionclone_amd import probe
+    M, N, K = 131072, 960, 320
+    args = (1, 2, 3, None, M, N, K, K, N, 1, 4, 5, None, 4096, 16, 1e-5, 6, None, 0, 0)
+    fam, fl, nb, shape = probe._cost("mc_norm_gemm_f16", args)
+    assert fam == "gemm4<K=320 streaming> LayerNorm + DENSE" and fl == 2.0 * M * N * K
+    assert nb == 2.0 * (M * K + N * K + M * N) and shape == (1, M, N, K, False)
+    fam, fl, nb, shape = probe._cost("mc_norm_gemm_f16", args[:9] + (2,) + args[10:18] + (0x200, 0))
+    assert fam.startswith("gemm4<K=320 streaming> GroupNorm") and nb == 2.0 * (2 * M * K + N * K + M * N // 2) and shape[-1] is True
+    assert probe._gemm_name(56, 0) == "gemm5<256x160 x2 per CU> DENSE" and probe._gemm_name(151, 1).endswith("CONV_S1 split-K + reduce")
