@@ -29,7 +29,10 @@ namespace mc {
 //   kind 1  LayerNorm over the K = 320 channels (+ the temporal position table): the lane pair (l, l + 32) holds one row,
 //           sum and sum of squares by v_dot2_f32_f16 (fp32) with one cross-lane add each, y = (x - mean) rstd gamma + beta
 //           [+ pe[frame]] in fp32, rounded to fp16 once - what ln_fwd5_kernel (norm.hip) computes, i.e. attention.py:189,206,212 /
-//           motion_module.py:204,210,237-246; (mean, rstd) optionally written for the backward;
+//           motion_module.py:204,210,237-246; (mean, rstd) optionally written for the backward.  The variance is
+//           E[x^2] - mean^2 from fp32 sums (ln_fwd5_kernel and torch subtract the mean first): relative error ~1e-7 (1 +
+//           mean^2 / var), i.e. it reaches the fp16 resolution of the output only for rows whose |mean| exceeds ~100 standard
+//           deviations - GroupNorm's statistics (gn_finalize / gn_block_stats) have always been computed this way;
 //   kind 2  GroupNorm WITHOUT activation (Transformer3DModel.norm / TemporalTransformer3DModel.norm, eps 1e-6): per frame an
 //           affine map x sc[k] + sh[k] (sc = rstd gamma, sh = beta - mean sc; the arithmetic of gn_apply_kernel); the
 //           statistics are finalised from the per-chunk partial sums in the prologue (gn_block_stats) and written for the
