@@ -803,3 +803,22 @@ def test_gemm5_two_workgroups_per_cu_geometry(backend):
     og = ops.gemm(a, ops.interleave_geglu(wg), bias=ops.interleave_geglu(bg.t()).t().contiguous(), geglu=True, cfg=9)
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "256x160 geglu")
     assert torch.equal(og, ops.gemm(a, ops.interleave_geglu(wg), bias=ops.interleave_geglu(bg.t()).t().contiguous(), geglu=True, cfg=11))
+
+
+def test_norm_gemm_layernorm_statistics_with_a_large_row_mean(backend):
+    """the fused LayerNorm takes var = E[x^2] - mean^2 from fp32 sums (the separate kernel subtracts the mean first): rows whose
+    mean is 16 standard deviations - far beyond what the UNet's hidden states show - still give rstd to 1e-4 of the exact value"""
+    dev = backend
+    M, K, N = 256, 320, 64
+    g = torch.Generator().manual_seed(12)
+    x = (8.0 + 0.5 * torch.randn(M, K, generator=g)).half().to(dev)
+    w = rnd((N, K), dev, 2, 0.05)
+    gamma, beta = torch.ones(K, device=dev), torch.zeros(K, device=dev)
+    out, stats = ops.norm_gemm(x, w, 1, gamma, beta, force=True)
+    xd = x.double().cpu()
+    mean, var = xd.mean(1), xd.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + 1e-5)
+    assert ((stats[:, 0].double().cpu() - mean).abs() / mean.abs()).max() < 1e-6
+    assert ((stats[:, 1].double().cpu() - rstd).abs() / rstd).max() < 1e-4
+    y = ((xd - mean[:, None]) * rstd[:, None]).half().double() @ w.double().cpu().t()
+    close(out, y, 2e-2, 1e-2, "fused LayerNorm + GEMM on rows with mean = 16 sigma")
