@@ -311,16 +311,16 @@ class UNet3DEngine:
         T1 = T // geo.B
         b0, b1 = self._brange(geo, gb)
         lo, hi = b0 * T1, b1 * T1
-        W1, b1 = w.lin(wname), w.vec(biasname).unsqueeze(0)
+        W1, bias1 = w.lin(wname), w.vec(biasname).unsqueeze(0)
         gg = ops.empty((T, W1.shape[0] // 2), h)
-        ls = ops.empty((T, 2), h, torch.float32)       # only rows lo .. hi (the differentiated batch element) are read later
-        r = ops.norm_gemm(h[lo:hi], W1, 1, g, b, bias=b1, stats=ls[lo:hi])
+        ls = ops.empty((T, 2), h, torch.float32)       # only rows lo .. hi (the differentiated batch elements) are read later
+        r = ops.norm_gemm(h[lo:hi], W1, 1, g, b, bias=bias1, stats=ls[lo:hi])
         n = None
         if r is not None:
             ff1 = r[0]
         else:                                          # outside the streaming kernel's shapes: LayerNorm, then the GEMMs
             n, ls = ops.layernorm_fwd(h, g, b, save_stats=True)
-            ff1 = ops.gemm(n[lo:hi], W1, bias=b1)
+            ff1 = ops.gemm(n[lo:hi], W1, bias=bias1)
         ops.geglu_fwd(ff1, out=gg[lo:hi])
         for a, e in ((0, lo), (hi, T)):
             if e <= a:
