@@ -62,7 +62,7 @@ class MotionCloneSampler:
         self.score_gs = float(score_guidance_scale)
         self._graphs = None      # step index -> (hipGraph, static input, static output); see enable_graphs()
         self._graph_pool = None
-        self._warm_kinds = set()  # {guided?} kinds of step that already ran once eagerly on this sampler (lazy init done)
+        self._warm_kinds = set()  # {(guided?, SparseCtrl?)} kinds of step that already ran once eagerly on this sampler (lazy init done)
 
     def _alphas(self, i):
         t = int(self.timesteps[i])
@@ -126,13 +126,14 @@ class MotionCloneSampler:
                 # weights, function attributes, workspace caches) must not happen inside a capture.  Later captures of the same
                 # kind skip it - an eager guided step allocates its whole tape from the ordinary caching pool, and doing that
                 # for all 30 step indices of every lane is what held 63 GiB reserved for 18 GiB in use (round 3).
-                if guided not in self._warm_kinds:
+                kind = (guided, ctrl is not None)      # the SparseCtrl encoder has its own lazily packed weights
+                if kind not in self._warm_kinds:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
                     with torch.cuda.stream(side):
                         self._step_eager(s_lat, i, s_text, s_rep, None, s_ctrl)
                     torch.cuda.current_stream().wait_stream(side)
-                    self._warm_kinds.add(guided)
+                    self._warm_kinds.add(kind)
                 graph = torch.cuda.CUDAGraph()
                 # thread_local: other host threads (launcher lanes) keep allocating / launching while this one captures
                 with torch.cuda.graph(graph, pool=self._graph_pool, capture_error_mode="thread_local"):
