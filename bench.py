@@ -214,6 +214,63 @@ def reference_gpu_baseline(dev, size=512, sched=(30, 18, 0.4)):
                                   "config-2 shape, schedule %s" % (torch.__version__, torch.cuda.get_device_name(0), list(sched)))
 
 
+TIMED_DURATIONS_FILE = os.path.join("profiles", "kernel_durations_timed.json")
+_G5_TILES = {(256, 320): "gemm5<256x320>", (128, 320): "gemm5<128x320>", (256, 160): "gemm5<256x160 x2 per CU>"}
+_MODE_NAMES = ["DENSE", "CONV_S1", "CONV_S2", "CONV_UP", "TCONV_S2"]
+
+
+def family_of_traced_kernel(name):
+    """rocprofv3 kernel name -> the probe's family name (motionclone_amd/probe.py) for the GEMM structures; None otherwise.
+    gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, stages> (EPI 1 = fused GEGLU and split-K launches are the same family as in
+    the probe, which names a GEMM by structure and mode only); gemm4_kernel<KS, GEGLU, NORM>."""
+    import re
+    m = re.search(r"gemm5_kernel<(\d+), (\d+), (\d+), (\d+), (\d+)", name)
+    if m:
+        mode, bm, bn = int(m.group(1)), int(m.group(4)), int(m.group(5))
+        base = _G5_TILES.get((bm, bn))
+        return "%s %s" % (base, _MODE_NAMES[mode]) if base and mode < len(_MODE_NAMES) else None
+    m = re.search(r"gemm4_kernel<(\d+), (\w+), (\d+)>", name)
+    if m:
+        return "gemm4<K=320 streaming> " + {0: "DENSE", 1: "LayerNorm + DENSE", 2: "GroupNorm + DENSE"}.get(int(m.group(3)), "?")
+    return None
+
+
+def timed_roofline(roof_all, prof):
+    """The dominant GEMM family IN THE TIMED REGIME (hipGraph replay, several videos in flight): HIP events cannot bracket
+    launches inside a graph replay, so the per-launch DURATION comes from a rocprofv3 --kernel-trace --stats run of this same
+    command (profiles/kernel_durations_timed.json, written by tools/kernel_stats_md.py from the round's profile run; its
+    `code` field names the commit) and the algorithmic FLOP per launch from this run's probe video, which issues the same
+    launch sequence with the same tile choice.  `overlap` = summed kernel time / wall time of the traced bench region: kernels
+    of the videos in flight share the CUs, so a kernel's own duration is longer than alone; achieved x overlap is the rate the
+    family's launches sustain per unit of GPU time they occupy."""
+    if not prof or not roof_all:
+        return None
+    groups = {}
+    for name, k in prof.get("kernels", {}).items():
+        fam = family_of_traced_kernel(name)
+        if fam is None:
+            continue
+        g = groups.setdefault(fam, dict(calls=0, total_us=0.0))
+        g["calls"] += k["calls"]
+        g["total_us"] += k["calls"] * k["avg_us"]
+    best = None
+    for fam, g in groups.items():
+        rows = [r for n, r in roof_all.items() if n == fam or n == fam + " split-K + reduce"]
+        if not rows or not g["calls"]:
+            continue
+        flop = sum(r["flop_per_launch"] * r["launches"] for r in rows) / sum(r["launches"] for r in rows)
+        if flop <= 0:
+            continue
+        avg_us = g["total_us"] / g["calls"]
+        tf = flop / avg_us / 1e6
+        row = dict(kernel=fam, bound="mfma", achieved=tf, peak=PEAK_FP16_MFMA_TFLOPS, unit="TFLOP/s", frac=tf / PEAK_FP16_MFMA_TFLOPS,
+                   avg_launch_us=avg_us, flop_per_launch=flop, share_of_kernel_time=g["total_us"] / 1e6 / prof["total_kernel_s"],
+                   overlap=prof.get("overlap"), regime=prof.get("regime"), source=TIMED_DURATIONS_FILE, code=prof.get("code"))
+        if best is None or row["share_of_kernel_time"] > best["share_of_kernel_time"]:
+            best = row
+    return best
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: replace this process by `torch.distributed.run` with N ranks on this
     node (one per GPU, rendezvous on 127.0.0.1 and a free port) running the same command line."""
@@ -233,13 +290,17 @@ def compact_line(res, detail_path, limit=4000):
     long.  Everything else (`roofline_by_kernel`, traffic per shape, VAE, eager loop, baselines) goes to `detail_path`."""
     keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "sec_per_guided_step", "sec_per_plain_step", "sec_per_denoise_step",
-            "e2e_tflops_per_gpu", "e2e_frac_of_mfma_peak"]
+            "e2e_tflops_per_gpu", "e2e_frac_of_mfma_peak", "videos_per_min_incl_vae"]
     line = {k: res[k] for k in keep if k in res}
     r = res.get("roofline")
     if r:
         line["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                   "traffic_vs_algorithmic", "avg_launch_us", "launches",
                                                   "share_of_probe_video")}
+    rt = res.get("roofline_timed")
+    if rt:
+        line["roofline_timed"] = {k: rt.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us", "overlap",
+                                                         "share_of_kernel_time", "source")}
     c = res.get("cpu_baseline")
     if c:
         line["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "cpu_model", "kind", "sample", "error")
@@ -255,21 +316,35 @@ def compact_line(res, detail_path, limit=4000):
     if "warmup_seconds" in res:
         line["cold_start_seconds"] = res["warmup_seconds"]     # warm-up videos incl. the graph captures of every lane
     line["detail"] = detail_path
+    # never let a long string cost the record (the whole benchmark has run by now): shed, in this order, the prose, the
+    # error texts, the optional objects, and finally cut the strings of the contract keys - a line is ALWAYS printed
+    sheds = [lambda: line.get("cpu_baseline", {}).pop("sample", None),
+             lambda: [c.__setitem__("error", str(c["error"])[:120]) for c in (line.get("cpu_baseline"),) if c and "error" in c],
+             lambda: line.pop("roofline_timed", None),
+             lambda: line.pop("cpu_baseline", None),
+             lambda: line.pop("roofline", None),
+             lambda: [line.pop(k, None) for k in list(line) if k not in keep and k != "detail"],
+             lambda: line.get("config", {}).__setitem__("workload", str(line.get("config", {}).get("workload", ""))[:160]),
+             lambda: line.__setitem__("metric", str(line.get("metric", ""))[:160]),
+             lambda: line.__setitem__("config", {"workload": str(line.get("config", {}).get("workload", ""))[:80]}),
+             lambda: [line.pop(k, None) for k in list(line) if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
+                                                                            "ms_per_step", "higher_is_better")]]
     out = json.dumps(line)
-    if len(out) > limit:      # never let a long string cost the record: drop the prose first
-        line.get("cpu_baseline", {}).pop("sample", None)
+    for shed in sheds:
+        if len(out) <= limit:
+            break
+        shed()
         out = json.dumps(line)
-    assert len(out) <= limit, len(out)
     return out
 
 
 def write_detail(res):
-    """full record -> profiles/r04_bench_detail.json (and gpurun_out/, which is what travels back from a GPU box)"""
-    rel = os.path.join("profiles", "r04_bench_detail.json")
+    """full record -> profiles/r05_bench_detail.json (and gpurun_out/, which is what travels back from a GPU box)"""
+    rel = os.path.join("profiles", "r05_bench_detail.json")
     for d in ("profiles", "gpurun_out"):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "r04_bench_detail.json"), "w") as f:
+            with open(os.path.join(ROOT, d, "r05_bench_detail.json"), "w") as f:
                 json.dump(res, f, indent=1)
         except OSError:
             pass
@@ -293,7 +368,11 @@ def main():
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
     ap.add_argument("--no-norm-fusion", action="store_true", help="A/B: LayerNorm / GroupNorm as separate launches in front of the "
                     "K = 320 GEMMs (the round-3 launch sequence) instead of mc_norm_gemm_f16")
-    ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r04_bench_detail.json")
+    ap.add_argument("--no-shared-prefix", action="store_true", help="A/B: feed the UNet the duplicated CFG batch [x | x] as rounds 1-4 did, "
+                    "instead of running what precedes the first cross-attention once for both halves (engine.forward: dup)")
+    ap.add_argument("--probe-one-lane", action="store_true", help="roofline probe video with the tile choice of ONE video in flight "
+                    "(round 4's probe regime) instead of the timed region's")
+    ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r05_bench_detail.json")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
     ap.add_argument("--batch", type=int, default=1, help="videos batched into ONE launch sequence per lane (latents [V, ...], text "
                     "[u_1 .. u_V | c_1 .. c_V]: the same kernels on V times the rows); --inflight lanes x --batch videos are in "
@@ -339,6 +418,7 @@ def main():
             sd[name] = flat[off:off + n].view(shape)
             off += n
     eng = UNet3DEngine(sd, cfg, dev)
+    eng.share_prefix = not args.no_shared_prefix
     N_STEPS, G_STEPS, G_SCALE = args.ddim_steps, args.guided_steps, args.guidance_scale
     ceng = None
     if args.sparsectrl:
@@ -452,10 +532,13 @@ def main():
         out_e = eager_lane0()
         torch.cuda.synchronize()
         te = (time.perf_counter() - te0) / VB
-        # the probe video runs with the tile / split-K choice of ONE video in flight (its regime), not the timed region's
-        ops.set_gemm_share(1)
-        one_video(sme, lat, text, vid, noise, ctrl=ctrl)              # the single-lane choice may touch new kernels: warm
-        torch.cuda.synchronize()
+        # Round 5: the probe video runs with the tile / split-K choice of the TIMED region (the kernels `value` is made of; round 4
+        # probed the one-video-in-flight choice, which moved the wide layers to another kernel and hid their HBM re-reads from
+        # the `roofline` row).  --probe-one-lane restores the old regime for tools.
+        if args.probe_one_lane:
+            ops.set_gemm_share(1)
+            one_video(sme, lat, text, vid, noise, ctrl=ctrl)          # the single-lane choice may touch new kernels: warm
+            torch.cuda.synchronize()
         probe.enabled = True
         tp0 = time.perf_counter()
         one_video(sme, lat, text, vid, noise, ctrl=ctrl)
@@ -508,7 +591,16 @@ def main():
         roof = None
         if roof_all:
             dom = max(roof_all, key=lambda n: roof_all[n]["share_of_probe_video"])   # dominant by time
-            roof = dict(roof_all[dom], kernel=dom)
+            roof = dict(roof_all[dom], kernel=dom, regime="one eager video, tile choice of %s" % (
+                "one video in flight" if args.probe_one_lane else "the timed region (%d in flight)" % NF))
+        roof_timed = None
+        tdf = os.path.join(ROOT, TIMED_DURATIONS_FILE)
+        if (os.path.exists(tdf) and (args.frames, args.size, N_STEPS, G_STEPS) == (16, 512, 30, 18) and use_graphs and NF == 3
+                and VB == 1 and not args.sparsectrl and not args.probe_one_lane):
+            try:
+                roof_timed = timed_roofline(roof_all, json.load(open(tdf)))
+            except Exception as e:   # noqa: BLE001  (a stale / malformed profile must not cost the record)
+                roof_timed = {"error": "%s: %s" % (type(e).__name__, e)}
         hbm = dict(peak_allocated_gib=timed_allocated, peak_reserved_gib=timed_reserved, videos_in_flight=NF,
                    whole_process_peak_reserved_gib=torch.cuda.max_memory_reserved(dev) / 2 ** 30,
                    note="torch caching allocator during the TIMED region (weights 2.4 GiB fp16 + packed copies, %d lanes: "
@@ -535,12 +627,14 @@ def main():
             "e2e_tflops_per_gpu": tflop_video * args.steps / elapsed,
             "e2e_frac_of_mfma_peak": tflop_video * args.steps / elapsed / PEAK_FP16_MFMA_TFLOPS,
             "roofline": roof,
+            "roofline_timed": roof_timed,
             "roofline_note": "per-launch HIP events around EVERY C-ABI launch of ONE eager video run after the timed region "
-                             "(events cannot bracket launches inside a graph replay), tile choice of one video in flight; each row's "
+                             "(events cannot bracket launches inside a graph replay), tile choice of the timed region; each row's "
                              "`bound` is the roof it is closer to (dense fp16 MFMA 2.5 PF vs HBM 8 TB/s, algorithmic flop / bytes); "
                              "`traffic` = PMC HBM bytes per launch on the shapes listed in roofline_traffic_by_shape (profiles/), null "
-                             "where not collected; per-kernel durations of the TIMED regime (graphs, videos in flight): rocprofv3 "
-                             "trace in profiles/r04_kernel_stats.md",
+                             "where not collected; `roofline_timed`: the dominant GEMM family with the per-launch duration of the TIMED "
+                             "regime (graphs, videos in flight) from the committed rocprofv3 kernel trace of this command "
+                             "(profiles/kernel_durations_timed.json, profiles/r05_kernel_stats.md)",
             "roofline_by_kernel": roof_all,
             "roofline_coverage_of_probe_video": probe.covered(probe_elapsed),
             "roofline_traffic_by_shape": traffic_rows,
@@ -566,6 +660,11 @@ def main():
                 res["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
         else:
             res["cpu_baseline"] = None
+        if vae_info and "decode_sec_per_video" in vae_info:
+            # BASELINE's metric is the UNet loop; a whole video also needs the reference video's VAE encode and the decode of the
+            # result (measured above, one video at a time, nothing overlapped): the conservative end-to-end figure
+            per_video = elapsed / args.steps + vae_info["decode_sec_per_video"] + vae_info["encode_sec_per_video"]
+            res["videos_per_min_incl_vae"] = world * 60.0 / per_video
         detail = write_detail(res) if not args.no_detail else None
         sys.stdout.flush()
         print(compact_line(res, detail), flush=True)

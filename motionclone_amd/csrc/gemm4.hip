@@ -429,7 +429,9 @@ static int launch4(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t bC, u
 // interleaved (h_j, gate_j), C gets N/2 columns).  nsplit = workgroups sharing one 256-row block of A (0 = automatic).
 // norm: null, or the normalisation applied to the rows of A in registers (G4Norm; no residual then).
 // Returns MC_ERR_UNSUPPORTED for anything else (the caller falls back to the tiled kernels).
-int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4Norm* norm) {
+// Every reason gemm4_dispatch can refuse a problem, without launching anything: mc_norm_gemm_f16 asks BEFORE it launches the
+// GroupNorm partial-sum pass, so that a refused call has done no work (its caller then runs norm and GEMM separately).
+int gemm4_check(const GemmParams& p, const G4Norm* norm) {
     if (p.A2 || p.K != 320 || p.N % G4_BN || (p.ws && !(p.dbg & 16)) || p.splits != 1) return MC_ERR_UNSUPPORTED;
     if (p.epi && (p.R || p.alpha != 1.0f)) return MC_ERR_UNSUPPORTED;
     if (p.bias && p.rows_per_batch < p.M) return MC_ERR_UNSUPPORTED;
@@ -446,8 +448,18 @@ int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4
     const size_t lim = 0x7FFFFFF0u;
     const size_t bA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bW = (size_t)p.N * p.K * 2;
     const size_t bC = ((size_t)(p.M - 1) * p.ldc + ncol) * 2;
-    const size_t bR = p.R ? ((size_t)(p.M - 1) * p.ldr + p.N) * 2 : 0, bB = (size_t)p.N * 4;
+    const size_t bR = p.R ? ((size_t)(p.M - 1) * p.ldr + p.N) * 2 : 0;
     if (bA > lim || bW > lim || bC > lim || bR > lim) return MC_ERR_UNSUPPORTED;
+    return MC_OK;
+}
+
+int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4Norm* norm) {
+    if (gemm4_check(p, norm) != MC_OK) return MC_ERR_UNSUPPORTED;
+    const int kind = norm ? norm->kind : 0;
+    const int ncol = p.epi ? p.N / 2 : p.N;
+    const size_t bA = ((size_t)(p.M - 1) * p.lda + p.K) * 2, bW = (size_t)p.N * p.K * 2;
+    const size_t bC = ((size_t)(p.M - 1) * p.ldc + ncol) * 2;
+    const size_t bR = p.R ? ((size_t)(p.M - 1) * p.ldr + p.N) * 2 : 0, bB = (size_t)p.N * 4;
     if (nsplit <= 0) {   // two workgroups per CU want >= 512 of them; more splits re-read A from L2, fewer idle CUs
         const int tilesM = (p.M + G4_BM - 1) / G4_BM;
         nsplit = 1;

@@ -12,6 +12,7 @@ namespace mc {
 int gemm2_dispatch(const GemmParams& p, int mode, int small_tile, int deep, size_t rowsA, hipStream_t stream);   // gemm2.hip
 int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStream_t stream);                    // gemm3.hip
 int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4Norm* norm = nullptr);          // gemm4.hip
+int gemm4_check(const GemmParams& p, const G4Norm* norm);                                                        // gemm4.hip
 int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStream_t stream);                    // gemm5.hip
 int gn_partial_launch(const void* a, int lda, int ctot, int frames, int hw, float* partial, hipStream_t stream);   // norm.hip
 }  // namespace mc
@@ -266,6 +267,9 @@ extern "C" int mc_norm_gemm_f16(const void* A, const void* W, void* C, const flo
         np.partial = partial;
         np.nchunk = mc_gn_nchunk(hw);
         np.gn_n = (float)hw * (K / 32);
+        // nothing is launched for a problem the fused kernel will refuse (2 GiB descriptor limits, alignment): the caller's
+        // fallback (GroupNorm, then GEMM) then runs the partial pass exactly once
+        if (gemm4_check(p, &np) != MC_OK) return MC_ERR_UNSUPPORTED;
         int rc = gn_partial_launch(A, lda, K, M / hw, hw, partial, s);
         if (rc != MC_OK) return rc;
     }

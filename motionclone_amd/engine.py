@@ -170,6 +170,26 @@ class Tape:
             fn()
         self.fns = []
 
+    def whole_batch(self):
+        """the same tape for modules whose forward ran on the differentiated batch elements ONLY (the shared prefix of a
+        duplicated batch, UNet3DEngine.forward(dup=True)): nothing is sliced there"""
+        return _WholeBatchTape(self)
+
+
+class _WholeBatchTape:
+    """Tape proxy with grad_batch = None; every other attribute (closures, gradients, grad_scale, latent_grad) is the tape's"""
+
+    def __init__(self, tape):
+        object.__setattr__(self, "_t", tape)
+
+    grad_batch = None
+
+    def __getattr__(self, k):
+        return getattr(self._t, k)
+
+    def __setattr__(self, k, v):
+        setattr(self._t, k, v)
+
 
 class UNet3DEngine:
     def __init__(self, state_dict, cfg=None, device="cuda", guidance_block=1, grad_scale=1024.0, guidance_blocks=None):
@@ -192,6 +212,9 @@ class UNet3DEngine:
                 raise NotImplementedError("motion_guidance_blocks entry %r cannot be honoured (last entry: %r)"
                                           % (blk, self.guidance_blocks[-1]))
         self.grad_scale = float(grad_scale)
+        # guided / plain steps feed the UNet a batch whose halves differ in the text only: run what precedes the first
+        # cross-attention once (forward: dup).  False = the duplicated batch of rounds 1-4 (A/B: bench.py --no-shared-prefix)
+        self.share_prefix = True
         self.G = self.cfg["norm_num_groups"]
         assert self.G == 32, "kernels are specialised for GroupNorm(32)"
         ch = self.cfg["block_out_channels"]
@@ -386,43 +409,59 @@ class UNet3DEngine:
             tape.add(bwd)
         return out
 
-    def _spatial(self, p, x, text2d, n_text, geo, tape):
-        """Transformer3DModel + BasicTransformerBlock (attention.py:95-142,256-300)"""
+    def _spatial(self, p, x, text2d, n_text, geo, tape, shared_geo=None):
+        """Transformer3DModel + BasicTransformerBlock (attention.py:95-142,256-300).
+
+        shared_geo (forward(dup=True)): the batch of `geo` is two copies of the same rows that differ in their text only
+        ([u_1 .. u_V | c_1 .. c_V] of the same latents, motionclone_functions.py:216-223,248-253) and `x` holds ONE copy
+        (geometry shared_geo, V batch elements).  Everything in front of the cross-attention - GroupNorm, proj_in, the
+        self-attention with its output projection, LayerNorm + attn2.to_q - does not see the text: it runs once on the V
+        elements and both halves use the result (the reference computes it twice with identical values).  The backward
+        differentiates the conditional half only, which IS the shared rows: nothing is sliced in front of the junction."""
         w, cfg = self.w, self.cfg
         heads = cfg["attention_heads"]
         C = x.shape[1]
         d = C // heads
         fr, hw, T = geo.frames, geo.hw, geo.T
+        gA = shared_geo if shared_geo is not None else geo
         b = p + "transformer_blocks.0."
         gN, bN = w.vec(p + "norm.weight"), w.vec(p + "norm.bias")
-        h0, st = self._gn_gemm(x, p + "norm.weight", p + "norm.bias", p + "proj_in.weight", p + "proj_in.bias", fr, hw)
+        h0, st = self._gn_gemm(x, p + "norm.weight", p + "norm.bias", p + "proj_in.weight", p + "proj_in.bias", gA.frames, hw)
         # self-attention
         qkv, ls1 = self._ln_gemm(h0, b + "norm1.weight", b + "norm1.bias",
                                  w.cat_lin([b + "attn1.to_q.weight", b + "attn1.to_k.weight", b + "attn1.to_v.weight"]), tape)
-        a1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], hw, hw, heads, d, fr,
+        a1, lse1 = ops.attn_fwd(qkv[:, :C], qkv[:, C:2 * C], qkv[:, 2 * C:], hw, hw, heads, d, gA.frames,
                                 need_lse=tape is not None)
         h1 = ops.gemm(a1, w.lin(b + "attn1.to_out.0.weight"), bias=w.vec(b + "attn1.to_out.0.bias").unsqueeze(0),
                       residual=h0)
         # cross-attention to the text (K/V are frame-invariant: computed once per batch element)
         q2, ls2 = self._ln_gemm(h1, b + "norm2.weight", b + "norm2.bias", w.lin(b + "attn2.to_q.weight"), tape)
+        if shared_geo is not None:     # the junction: both halves continue from the same rows
+            h1B, q2B, xB = torch.cat([h1, h1], 0), torch.cat([q2, q2], 0), torch.cat([x, x], 0)
+        else:
+            h1B, q2B, xB = h1, q2, x
         kv = ops.gemm(text2d, w.cat_lin([b + "attn2.to_k.weight", b + "attn2.to_v.weight"]))
-        a2, lse2 = ops.attn_fwd(q2, kv[:, :C], kv[:, C:], hw, n_text, heads, d, fr, kv_bdiv=geo.F,
+        a2, lse2 = ops.attn_fwd(q2B, kv[:, :C], kv[:, C:], hw, n_text, heads, d, fr, kv_bdiv=geo.F,
                                 need_lse=tape is not None)
         h2 = ops.gemm(a2, w.lin(b + "attn2.to_out.0.weight"), bias=w.vec(b + "attn2.to_out.0.bias").unsqueeze(0),
-                      residual=h1)
+                      residual=h1B)
+        del h1B, q2B
         # GEGLU feed-forward
         gg, bff1, ls3 = self._ff_geglu(h2, b + "norm3.weight", b + "norm3.bias", b, geo, tape)
         h3 = ops.gemm(gg, w.lin(b + "ff.net.2.weight"), bias=w.vec(b + "ff.net.2.bias").unsqueeze(0), residual=h2)
         del gg
-        out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=x)
+        out = ops.gemm(h3, w.lin(p + "proj_out.weight"), bias=w.vec(p + "proj_out.bias").unsqueeze(0), residual=xB)
+        del xB
         if tape is None:
             return out
 
         g1, cut = self._bslice(geo, tape.grad_batch)
-        bx, bst, bh0, bh1, bh2 = cut(x), cut(st), cut(h0), cut(h1), cut(h2)
-        bls1, bls2, bls3, bqkv, ba1, blse1 = cut(ls1), cut(ls2), cut(ls3), cut(qkv), cut(a1), cut(lse1)
-        bq2, bkv, ba2, blse2 = cut(q2), cut(kv), cut(a2), cut(lse2)   # (bff1: already the differentiated rows)
+        cutA = (lambda t: t) if shared_geo is not None else cut      # tensors in front of the junction hold the shared rows
+        bx, bst, bh0, bh1, bh2 = cutA(x), cutA(st), cutA(h0), cutA(h1), cut(h2)
+        bls1, bls2, bls3, bqkv, ba1, blse1 = cutA(ls1), cutA(ls2), cut(ls3), cutA(qkv), cutA(a1), cutA(lse1)
+        bq2, bkv, ba2, blse2 = cutA(q2), cut(kv), cut(a2), cut(lse2)   # (bff1: already the differentiated rows)
         fr1, hw1, T1 = g1.frames, g1.hw, g1.T
+        assert bx.shape[0] == T1 and bq2.shape[0] == T1 and ba2.shape[0] == T1
 
         def bwd():
             dout = tape.take(out)
@@ -564,27 +603,46 @@ class UNet3DEngine:
     # ---- whole network --------------------------------------------------------------------------------
     @ops.scoped
     def forward(self, latents, t, text, tape=None, record=None, seeds=None, only_motion_feature=False,
-                down_residuals=None, mid_residual=None):
+                down_residuals=None, mid_residual=None, dup=False):
         """latents [B, 4, F, H, W] fp16, text [B, n_text, xdim] fp16 -> eps as a token matrix [(b f y x), 4].
         With `tape`, the blocks up to up_blocks[guidance_block] record their backward (motionclone_functions.py
-        :601-625); later blocks never do (the reference runs them under no_grad, :629-652)."""
+        :601-625); later blocks never do (the reference runs them under no_grad, :629-652).
+
+        dup=True (round 5): latents [V, 4, F, H, W] stand for the batch [x_1 .. x_V | x_1 .. x_V] with text [2 V, ...] =
+        [u_1 .. u_V | c_1 .. c_V] - what single_step_video feeds the UNet (`noisy.expand(2, ...)` at :248-253; the two B = 1
+        calls on equal latents at :216-223).  The two halves differ in their text only, and the text enters at the first
+        cross-attention: conv_in, the first ResnetBlock3D and the first transformer's self-attention part give the same
+        values for both halves, so they run ONCE on the V elements (_spatial: shared_geo); from the junction on the batch is
+        2 V.  Same values as the duplicated batch up to the fp32 summation order of a GEMM whose tile choice follows the row
+        count (tests/test_engine_parity.py)."""
         cfg, w = self.cfg, self.w
         assert latents.dtype == torch.float16 and text.dtype == torch.float16
         B, CL, F, H, W = latents.shape
         L = cfg["layers_per_block"]
+        geoA = None                  # geometry of the shared prefix (dup): V batch elements
+        if dup:
+            if text.shape[0] != 2 * B:
+                raise ValueError("forward(dup=True): %d latents need text [%d, ...], got %s" % (B, 2 * B, tuple(text.shape)))
+            if cfg["down_has_attn"][0]:
+                geoA = Geo(B, F, H, W)
+            else:                    # no cross-attention in the first block: nothing to share the way _spatial does
+                latents = torch.cat([latents, latents], 0)
+            B = 2 * B
         geo = Geo(B, F, H, W)
         n_text = text.shape[1]
         text2d = text.reshape(B * n_text, text.shape[2]).contiguous()
         tb_all = self._time_bias(t, B, latents)
         gb = self.guidance_block
+        tapeA = tape.whole_batch() if (geoA is not None and tape is not None) else tape
 
         def hook(nm):   # classify_blocks (util.py:434-440) matches the FULL attention-module names by substring: a motion
             # module is hooked when any of its attentions is (entries longer than the module prefix included)
             return any(self._hooked(nm + ".temporal_transformer.transformer_blocks.0.attention_blocks.%d" % a) for a in (0, 1))
 
+        geo_in = geoA if geoA is not None else geo
         x_in = ops.latent_to_cl(latents, CIN_PAD)
         x = ops.gemm(x_in, w.conv("conv_in.weight", CIN_PAD), bias=w.vec("conv_in.bias").unsqueeze(0), mode=CONV_S1,
-                     geom=(H, W, H, W), m_out=geo.T)
+                     geom=(H, W, H, W), m_out=geo_in.T)
         if tape is not None:
             x0 = x
 
@@ -592,18 +650,30 @@ class UNet3DEngine:
                 dout = tape.take(x0)
                 if dout is None:
                     return
-                b0, b1 = self._brange(geo, tape.grad_batch)
+                b0, b1 = self._brange(geo_in, tapeA.grad_batch)
                 nb = b1 - b0
                 dxin = ops.gemm(dout, w.conv_dgrad("conv_in.weight", pad_cin=CIN_PAD), mode=CONV_S1,
                                 geom=(H, W, H, W), m_out=nb * F * H * W)
                 tape.latent_grad = ops.cl_to_latent(dxin, nb, CL, F, H, W, scale=1.0 / tape.grad_scale, f32=True)
             tape.add(bwd_in)
-        skips = [(x, geo)]
+        if geoA is not None:
+            # the skip copy of conv_in's output serves both halves of the batch; gradients (all of the differentiated,
+            # i.e. shared, rows) pass straight through to the one copy
+            xs = torch.cat([x, x], 0)
+            if tape is not None:
+                tape.add(lambda xs=xs, x0=x: (lambda g: tape.give(x0, g) if g is not None else None)(tape.take(xs)))
+            skips = [(xs, geo)]
+        else:
+            skips = [(x, geo)]
         for i in range(4):
             for j in range(L):
-                x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, tape)
-                if cfg["down_has_attn"][i]:
-                    x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, tape)
+                if geoA is not None and i == 0 and j == 0:      # the shared prefix (see the docstring)
+                    x = self._resnet("down_blocks.0.resnets.0.", x, None, tb_all, geoA, tapeA)
+                    x = self._spatial("down_blocks.0.attentions.0.", x, text2d, n_text, geo, tape, shared_geo=geoA)
+                else:
+                    x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, tape)
+                    if cfg["down_has_attn"][i]:
+                        x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, tape)
                 nm = "down_blocks.%d.motion_modules.%d" % (i, j)
                 x = self._motion(nm, x, geo, tape, record if hook(nm) else None, seeds if hook(nm) else None)
                 skips.append((x, geo))
@@ -723,9 +793,14 @@ class UNet3DEngine:
             seeds[name] = (idx, val, tape.grad_scale * float(weight) * 2.0 / numel)
         record = {}
         if batched:
-            lat2 = latents.expand(2, -1, -1, -1, -1) if V == 1 else torch.cat([latents, latents], 0)
-            eps2 = self.forward(lat2, t, torch.cat([text_uncond, text_cond], 0), tape=tape,
-                                record=record, seeds=seeds, down_residuals=down_residuals, mid_residual=mid_residual)
+            text2 = torch.cat([text_uncond, text_cond], 0)
+            if self.share_prefix:    # [u_1 .. u_V | c_1 .. c_V] on the same latents: what does not see the text runs once
+                eps2 = self.forward(latents, t, text2, tape=tape, record=record, seeds=seeds, down_residuals=down_residuals,
+                                    mid_residual=mid_residual, dup=True)
+            else:
+                lat2 = latents.expand(2, -1, -1, -1, -1) if V == 1 else torch.cat([latents, latents], 0)
+                eps2 = self.forward(lat2, t, text2, tape=tape, record=record, seeds=seeds, down_residuals=down_residuals,
+                                    mid_residual=mid_residual)
             T1 = eps2.shape[0] // 2
             eps_u, eps_c = eps2[:T1], eps2[T1:]
         else:
@@ -818,13 +893,21 @@ class ControlNetEngine(UNet3DEngine):
         text2d = text.reshape(B * n_text, text.shape[2]).contiguous()
         tb_all = self._time_bias(t, B, text)
         e = self._cond_embedding(cond, mask, F, H, W)
-        x = torch.cat([e] * B, dim=0) if B > 1 else e     # the same condition for every batch element
-        feats = [x]
+        # the same condition for every batch element: the batch elements differ in their text only, so (as in
+        # UNet3DEngine.forward(dup=True)) what precedes the first cross-attention runs once for a [u | c] batch
+        share = self.share_prefix and B == 2 and cfg["down_has_attn"][0]
+        geoA = Geo(1, F, H, W) if share else None
+        feats = [torch.cat([e] * B, dim=0) if B > 1 else e]
+        x = e if share else feats[0]
         for i in range(4):
             for j in range(L):
-                x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, None)
-                if cfg["down_has_attn"][i]:
-                    x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, None)
+                if share and i == 0 and j == 0:
+                    x = self._resnet("down_blocks.0.resnets.0.", x, None, tb_all, geoA, None)
+                    x = self._spatial("down_blocks.0.attentions.0.", x, text2d, n_text, geo, None, shared_geo=geoA)
+                else:
+                    x = self._resnet("down_blocks.%d.resnets.%d." % (i, j), x, None, tb_all, geo, None)
+                    if cfg["down_has_attn"][i]:
+                        x = self._spatial("down_blocks.%d.attentions.%d." % (i, j), x, text2d, n_text, geo, None)
                 x = self._motion("down_blocks.%d.motion_modules.%d" % (i, j), x, geo, None, None, None)
                 feats.append(x)
             if i < 3:

@@ -231,7 +231,12 @@ def layernorm_bwd(dy, x, stats, gamma, add=None, out=None):
 
 
 # ---- norm + Linear in one launch (K = 320 level) -------------------------------------------------------
-NORM_GEMM_MIN_ROWS = 32768    # below this the streaming kernel does not fill the chip (gemm_api.hip's own rule for K = 320)
+# Below this the streaming kernel does not fill the chip.  NOT gemm_api.hip's rule for a plain K = 320 GEMM (that one keeps
+# N = 320 on the tiled kernels until M >= 98304): with the norm inside, the fused launch was measured faster than norm + GEMM
+# at every (M, N) the engine produces from 32768 rows up - N = 320: 38.1 vs 56.5 us (LayerNorm + q) and 50.0 vs 72.8 us
+# (GroupNorm + proj_in) at M = 65536, 25.2 vs 33.3 / 34.9 vs 47.9 at M = 32768 (profiles/r04_norm_gemm_microbench.jsonl);
+# M = 65536 is what the shared prefix of the CFG batch runs at config 2 (engine.forward: dup), M = 32768 config 1's B = 2.
+NORM_GEMM_MIN_ROWS = 32768
 
 
 def norm_gemm(x, w, kind, gamma, beta, *, bias=None, pe=None, hw=0, eps=1e-5, save_stats=True, geglu=False, out=None,

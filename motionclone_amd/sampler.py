@@ -62,7 +62,7 @@ class MotionCloneSampler:
         self.score_gs = float(score_guidance_scale)
         self._graphs = None      # step index -> (hipGraph, static input, static output); see enable_graphs()
         self._graph_pool = None
-        self._warm_kinds = set()  # {(guided?, SparseCtrl?)} kinds of step that already ran once eagerly on this sampler (lazy init done)
+        self._warm_kinds = set()  # {(guided?, SparseCtrl?, latent shape, text shape, GEMM share)} kinds of step that already ran once eagerly on this sampler
 
     def _alphas(self, i):
         t = int(self.timesteps[i])
@@ -126,7 +126,9 @@ class MotionCloneSampler:
                 # weights, function attributes, workspace caches) must not happen inside a capture.  Later captures of the same
                 # kind skip it - an eager guided step allocates its whole tape from the ordinary caching pool, and doing that
                 # for all 30 step indices of every lane is what held 63 GiB reserved for 18 GiB in use (round 3).
-                kind = (guided, ctrl is not None)      # the SparseCtrl encoder has its own lazily packed weights
+                # the graph key without the step index: a new resolution, batch size or GEMM share setting touches kernels and
+                # GEMM geometries (e.g. the two-workgroup tiles, chosen only for share 0) that have not run eagerly yet
+                kind = (guided, ctrl is not None, tuple(latents.shape), tuple(text.shape), ops._GEMM_SHARE)
                 if kind not in self._warm_kinds:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())
@@ -231,8 +233,11 @@ class MotionCloneSampler:
                 aux.update(eps_u=eps_u, eps_c=eps_c, grad=grad, loss=loss)
             coef = self.score_gs * (1.0 - a_t) ** 0.5
             return update(eps_c, eps_u, grad, coef)
-        lat2 = latents.expand(2, -1, -1, -1, -1) if V == 1 else torch.cat([latents, latents], 0)
-        eps2 = eng.forward(lat2, t, text, down_residuals=down, mid_residual=mid)
+        if eng.share_prefix:     # both halves of the CFG batch are the same latents: the text-free prefix runs once
+            eps2 = eng.forward(latents, t, text, down_residuals=down, mid_residual=mid, dup=True)
+        else:
+            lat2 = latents.expand(2, -1, -1, -1, -1) if V == 1 else torch.cat([latents, latents], 0)
+            eps2 = eng.forward(lat2, t, text, down_residuals=down, mid_residual=mid)
         T1 = eps2.shape[0] // 2
         if aux is not None:
             aux.update(eps_u=eps2[:T1], eps_c=eps2[T1:])

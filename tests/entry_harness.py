@@ -175,7 +175,15 @@ def write_tokenizer(path):
     json.dump({"model_max_length": 77, "tokenizer_class": "CLIPTokenizer"}, open(os.path.join(path, "tokenizer_config.json"), "w"))
 
 
-def write_assets(work, kind, n_examples=1):
+# configs/t2v_camera.jsonl:1-8 of the reference = BASELINE config 3's eight (prompt, reference-video) pairs, one per GPU:
+# (reference video, new_prompt, seed or None = the script's --default-seed).  Three distinct videos, four distinct seeds.
+CAMERA8 = [("camera_zoom_in", "Relics on the seabed", 42), ("camera_zoom_in", "A road in the mountain", 42),
+           ("camera_zoom_in", "Caves, a path for exploration", 2026), ("camera_zoom_in", "Railway for train", None),
+           ("camera_zoom_out", "Tree, in the mountain", 2026), ("camera_zoom_out", "Red car on the track", 2026),
+           ("camera_zoom_out", "Man, standing in his garden.", 2026), ("camera_1", "A island, on the ocean, sunny day", None)]
+
+
+def write_assets(work, kind, n_examples=1, camera8=False):
     from motionclone_amd.models.clip import clip_param_shapes
     from oracle import unet3d_ref as U
     from oracle import vae_ref as V
@@ -249,6 +257,17 @@ def write_assets(work, kind, n_examples=1):
         Image.fromarray(rng.randint(0, 256, size=(px, px, 3)).astype(np.uint8)).save(img)
         example.update(condition_image_paths=[img], image_index=[0], controlnet_scale=0.8)
     yaml.safe_dump(infer, open(os.path.join(work, "infer.yaml"), "w"))
+    if camera8:
+        assert kind == "t2v"
+        for n, stem in enumerate(sorted({c[0] for c in CAMERA8})):
+            np.save(os.path.join(work, stem + ".mp4.npy"), np.random.RandomState(30 + n).randint(0, 256, size=(9, 20, 24, 3)).astype(np.uint8))
+        with open(os.path.join(work, "examples.jsonl"), "w") as f:
+            for stem, prompt, seed in CAMERA8:
+                line = dict(video_path=os.path.join(work, stem + ".mp4"), new_prompt=prompt)
+                if seed is not None:
+                    line["seed"] = seed
+                f.write(json.dumps(line) + "\n")
+        return cfg
     with open(os.path.join(work, "examples.jsonl"), "w") as f:
         f.write(json.dumps(example) + "\n")
         for n in range(1, n_examples):     # same reference video (the .pt is overwritten per example, as in the reference)
@@ -292,7 +311,8 @@ def install_recorders(rec):
 
 
 def main():
-    """entry_harness.py KIND WORKDIR [--examples N] [--launch [--lanes K]]   (--launch: through motionclone_amd.launch, sharded
+    """entry_harness.py KIND WORKDIR [--examples N | --camera8] [--launch [--lanes K]]   (--camera8: the eight lines of the
+    reference's configs/t2v_camera.jsonl as the examples file; --launch: through motionclone_amd.launch, sharded
     over the torchrun environment's ranks and K lanes per rank; the assets must already exist in WORKDIR, outputs go to
     WORKDIR/videos_rank<r>)"""
     kind, work = sys.argv[1], os.path.abspath(sys.argv[2])
@@ -308,7 +328,7 @@ def main():
         map_cuda_to_cpu()
     written = install_stubs(work)
     if not launch:
-        write_assets(work, kind, n_examples)
+        write_assets(work, kind, n_examples, camera8="--camera8" in sys.argv)
     rec = {}
     install_recorders(rec)
     script = os.path.join(REFERENCE_ROOT, "t2v_video_sample.py" if kind == "t2v" else "i2v_video_sample.py")

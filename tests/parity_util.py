@@ -19,10 +19,14 @@ HP = dict(cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_u
 # 1.8e-3, gradient 6.4e-3 .. 7.6e-3, loss 1e-4 .. 3.3e-4, tie gap <= 3e-4, flips <= 0.31 % of the rows) so that a 3x regression
 # fails; the counts move by a few rows from run to run of the ORACLE (its fp32 GEMMs pick different split-K orders per shape).
 TOL_FWD, TOL_GRAD, TOL_LOSS = 5e-3, 2e-2, 2e-3
+# Round 5 (verdict item 5c): the full-size cases pass their own gradient bound = 2x what is measured on MI355X - 6.5e-3 .. 7.9e-3
+# at configs 1 / 2 / 4 and F = 32 -> 1.2e-2; 1.13e-2 at config 5's real size (|grad| <= 6e-6 there) -> 1.5e-2.  TOL_GRAD stays
+# the bound of the tiny simulator cases (few elements: the relative L2 of a 4 x 4 map is noisier).
+TOL_GRAD_FULLSIZE, TOL_GRAD_CONFIG5 = 1.2e-2, 1.5e-2
 TIE_GAP = 5e-4                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
 #                                                     (round 4: 1e-3 -> 5e-4; the worst gap ever measured is 3.4e-4)
 MAX_FLIP_FRACTION = 5e-3
-REPORT_FILE = "parity_r04.json"
+REPORT_FILE = "parity_r05.json"
 
 _REPORT = {}
 
@@ -129,7 +133,17 @@ def check_extraction(eng, smp, sdo, cfg, vid, noise, text, key, ctrl=None, res=N
     return rep, ref, prob
 
 
-def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, ctrl=None, res_u=None, res_c=None):
+def fp16_weights(sd):
+    """the reference's own arithmetic: the same parameters in fp16 for the oracle run in fp16 through stock PyTorch-ROCm"""
+    return {k: v.half() for k, v in sd.items()}
+
+
+def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, ctrl=None, res_u=None, res_c=None,
+                      tol_grad=None, witness_sd16=None):
+    """witness_sd16 (round 5, SURVEY.md 8c "second witness"): the oracle once more in fp16 on the device (= what the reference
+    computes through stock PyTorch: fp16 activations AND an fp16 autograd backward) - its loss / gradient / latents are
+    reported next to the engine's, both measured from the fp32 oracle."""
+    tol_grad = TOL_GRAD if tol_grad is None else tol_grad
     ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
     assert smp.timesteps.tolist() == ts.tolist()
     hp = dict(HP, guidance_steps=smp.G)
@@ -145,10 +159,24 @@ def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, c
              grad=rel(aux["grad"], ref_aux["grad"]), latents=rel(nxt, ref_nxt),
              loss_value=float(ref_aux["loss"]), grad_abs_max=float(ref_aux["grad"].abs().max()))
     report(key, **{"guided_" + k: v for k, v in e.items()})
+    if witness_sd16 is not None:
+        h = lambda r: None if r is None else ([t.half() for t in r[0]], r[1].half())   # noqa: E731
+        rep16 = {k: [v[0].half(), v[1]] for k, v in rep_ref.items()}
+        with oracle_mode(lat.device):
+            w_nxt, w_aux = G.guided_step(witness_sd16, cfg, lat.half(), step_index, ts, text.half(), rep16, hp,
+                                         res_u=h(res_u), res_c=h(res_c))
+        gnorm = float(w_aux["grad"].float().norm())
+        wit = dict(loss=abs(float(w_aux["loss"]) - float(ref_aux["loss"])) / abs(float(ref_aux["loss"])),
+                   grad=rel(w_aux["grad"], ref_aux["grad"]) if gnorm == gnorm else float("nan"),
+                   latents=rel(w_nxt, ref_nxt), eps_c=rel(w_aux["eps_c"], ref_aux["eps_c"]),
+                   grad_finite=bool(torch.isfinite(w_aux["grad"]).all()),
+                   grad_zero_fraction=float((w_aux["grad"] == 0).float().mean()))
+        report(key, **{"witness_fp16_oracle_guided_" + k: v for k, v in wit.items()})
+        del w_nxt, w_aux
     assert torch.isfinite(aux["grad"]).all() and torch.isfinite(nxt.float()).all()
     assert e["eps_c"] < TOL_FWD and e["eps_u"] < TOL_FWD, e
     assert e["loss"] < TOL_LOSS, e
-    assert e["grad"] < TOL_GRAD, e
+    assert e["grad"] < tol_grad, e
     assert e["latents"] < TOL_FWD, e
     return nxt, ref_nxt
 
@@ -168,11 +196,14 @@ def check_plain_step(eng, smp, sdo, cfg, lat, text, step_index, key, ctrl=None, 
     return nxt, ref_nxt
 
 
-def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=None, start_ref=None, ctrl=None, csdo=None):
+def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=None, start_ref=None, ctrl=None, csdo=None,
+               witness_sd16=None):
     """Steps [first, last) of the loop (sample_video, motionclone_functions.py:164-166): engine and oracle each follow
     their OWN trajectory from a common start (`start_ref`: fp32 latents at step `first`, default the initial noise).
     ctrl / csdo: SparseCtrl condition and the ControlNet's oracle weights - the encoder runs every step on the current
-    timestep (motionclone_functions.py:176-197), on both sides."""
+    timestep (motionclone_functions.py:176-197), on both sides.
+    witness_sd16 (round 5): a THIRD trajectory - the oracle in fp16 (the reference's arithmetic through stock PyTorch), its
+    drift from the fp32 oracle reported per step next to the engine's (not with SparseCtrl)."""
     ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
     hp = dict(HP, guidance_steps=smp.G)
     rep_dev = eng.prepare_representation(rep_ref)
@@ -180,6 +211,9 @@ def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=N
     xr = lat.float() if start_ref is None else start_ref.float()
     x = xr.half()
     drift = []
+    wdrift = []
+    xw = xr.half() if witness_sd16 is not None else None
+    rep16 = {k: [v[0].half(), v[1]] for k, v in rep_ref.items()} if witness_sd16 is not None else None
     shape2 = (2,) + tuple(lat.shape[1:])
     for i in range(first, last):
         x = smp.step(x, i, text, rep_dev, ctrl=ctrl)
@@ -195,8 +229,18 @@ def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=N
                                       res_c=([t[[1]] for t in d], m[[1]]) if d else None)
             else:
                 xr, _ = G.plain_step_full(sdo, cfg, xr, i, ts, text.float(), hp["cfg_scale"], res=(d, m) if d else None)
+            if xw is not None:
+                assert ctrl is None
+                if i < smp.G:
+                    xw, _ = G.guided_step(witness_sd16, cfg, xw, i, ts, text.half(), rep16, hp)
+                else:
+                    xw, _ = G.plain_step_full(witness_sd16, cfg, xw, i, ts, text.half(), hp["cfg_scale"])
+                wdrift.append(rel(xw, xr))
         drift.append(rel(x, xr))
     report(key, loop_drift=[round(d, 6) for d in drift], loop_steps=[first, last], loop_schedule=[smp.N, smp.G])
+    if wdrift:
+        report(key, witness_fp16_oracle_loop_drift=[round(d, 6) for d in wdrift],
+               witness_fp16_oracle_finite=bool(torch.isfinite(xw.float()).all()))
     assert torch.isfinite(x.float()).all()
     assert max(drift) < tol, drift
     return drift

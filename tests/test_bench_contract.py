@@ -48,7 +48,7 @@ def _full_record():
 def test_the_printed_line_is_small_and_complete(bench):
     res = _full_record()
     assert len(json.dumps(res)) > 20000                      # the record that overflowed the driver's capture
-    line = bench.compact_line(res, "profiles/r04_bench_detail.json")
+    line = bench.compact_line(res, "profiles/r05_bench_detail.json")
     assert len(line) <= 4000 and "\n" not in line
     got = json.loads(line)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
@@ -62,6 +62,72 @@ def test_the_printed_line_is_small_and_complete(bench):
     c = got["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] == 32 and c["value"] > 0 and "cpu_model" in c and "sample" in c
     assert "roofline_by_kernel" not in got and "roofline_traffic_by_shape" not in got
+
+
+def test_the_timed_regime_row_is_built_from_the_committed_kernel_trace_and_pinned_in_the_line(bench):
+    """roofline_timed (round 5): per-launch duration of the TIMED regime from a rocprofv3 kernel trace of the same command
+    (profiles/kernel_durations_timed.json), algorithmic FLOP per launch from the probe video; split-K and GEGLU launches of a
+    structure belong to its family, as in the probe."""
+    fam = "gemm5<256x320> DENSE"
+    row = lambda n, fl: dict(launches=n, flop_per_launch=fl, share_of_probe_video=0.2)   # noqa: E731
+    roof_all = {fam: row(3000, 60e9), fam + " split-K + reduce": row(1000, 100e9), "gemm5<256x320> CONV_S1": row(1200, 300e9),
+                "attn_fwd_ring self d=40 Nk=4096": row(300, 700e9)}
+    prof = dict(regime="test", total_kernel_s=2.0, overlap=1.4, code="abc1234", kernels={
+        "gemm5_kernel<0, 0, 0, 256, 320, 8, 4>": dict(calls=30000, avg_us=20.0),
+        "gemm5_kernel<0, 1, 0, 256, 320, 8, 4>": dict(calls=10000, avg_us=40.0),     # fused GEGLU: same family
+        "gemm5_kernel<1, 0, 0, 256, 320, 8, 4>": dict(calls=1000, avg_us=260.0),
+        "gn_apply_kernel": dict(calls=999, avg_us=25.0)})
+    assert bench.family_of_traced_kernel("void mc::gemm5_kernel<3, 0, 0, 256, 320, 8, 4>(mc::GemmParams)") == "gemm5<256x320> CONV_UP"
+    assert bench.family_of_traced_kernel("gemm5_kernel<0, 0, 0, 256, 160, 4, 3>") == "gemm5<256x160 x2 per CU> DENSE"
+    assert bench.family_of_traced_kernel("gemm4_kernel<20, true, 1>") == "gemm4<K=320 streaming> LayerNorm + DENSE"
+    assert bench.family_of_traced_kernel("gn_partial_kernel") is None
+    rt = bench.timed_roofline(roof_all, prof)
+    assert rt["kernel"] == fam and abs(rt["avg_launch_us"] - 25.0) < 1e-9
+    assert abs(rt["flop_per_launch"] - 70e9) < 1 and abs(rt["achieved"] - 70e9 / 25.0 / 1e6) < 1e-6
+    assert abs(rt["frac"] - rt["achieved"] / 2500.0) < 1e-12 and abs(rt["share_of_kernel_time"] - 0.5) < 1e-9 and rt["overlap"] == 1.4
+    assert bench.timed_roofline(roof_all, None) is None and bench.timed_roofline({}, prof) is None
+    res = _full_record()
+    res["roofline_timed"] = rt
+    got = json.loads(bench.compact_line(res, "profiles/r05_bench_detail.json"))
+    for k in ("kernel", "achieved", "frac", "avg_launch_us", "overlap", "share_of_kernel_time", "source"):
+        assert k in got["roofline_timed"], k
+
+
+def test_a_line_is_printed_whatever_the_strings_are(bench):
+    """compact_line never raises after the benchmark has run (round-4 advice): oversized strings are shed progressively and
+    the contract keys survive"""
+    res = _full_record()
+    res["metric"] = "m" * 3000
+    res["config"]["workload"] = "w" * 3000
+    res["cpu_baseline"] = {"error": "RuntimeError: " + "x" * 5000}
+    res["roofline"]["kernel"] = "k" * 3000
+    line = bench.compact_line(res, "profiles/r05_bench_detail.json")
+    assert len(line) <= 4000
+    got = json.loads(line)
+    assert got["value"] == 34.2 and got["unit"] == "videos/min" and got["metric"].startswith("m") and got["n_gpus"] == 1
+
+
+def test_bench_gpus_8_is_the_eight_rank_job_of_config_3(bench, monkeypatch):
+    """BASELINE config 3 = `bench.py --gpus 8`: without a launcher it becomes the 8-rank torch.distributed.run job on
+    127.0.0.1 (one rank per GPU, replicas); with the driver's launcher environment the world size must match."""
+    seen = {}
+
+    def fake_execv(exe, argv):
+        seen["argv"] = list(argv)
+        raise SystemExit(0)
+    monkeypatch.setattr(os, "execv", fake_execv)
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"])
+    with pytest.raises(SystemExit):
+        bench.main()
+    a = seen["argv"]
+    assert a[a.index("--nproc-per-node") + 1] == "8" and a[a.index("--master-addr") + 1] == "127.0.0.1" and "--nnodes=1" in a
+    assert a[a.index(os.path.join(ROOT, "bench.py")) + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8"])
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert "WORLD_SIZE=4" in str(e.value) and "--gpus 8" in str(e.value)
 
 
 def test_a_failed_baseline_leg_still_gives_a_parsable_line(bench):

@@ -285,3 +285,49 @@ def test_videos_batched_in_one_launch_sequence_match_their_separate_steps(backen
     assert a.shape[0] == 2
     for v in range(2):
         assert rel_err(a[v:v + 1], b[v]) < 5e-3, rel_err(a[v:v + 1], b[v])
+
+
+@pytest.mark.parametrize("V", [1, 2])
+def test_shared_prefix_of_the_cfg_batch_equals_the_duplicated_batch(backend, tiny, V):
+    """forward(dup=True) (round 5): the CFG batch [u_1 .. u_V | c_1 .. c_V] holds the same latents twice
+    (motionclone_functions.py:216-223,248-253), so conv_in, the first ResnetBlock3D and the text-free part of the first
+    transformer run ONCE on V elements.  Same eps as the duplicated batch (to the fp32 summation order of GEMMs whose tile
+    choice follows the row count), same guidance gradient, and both against the oracle; the engine's A/B switch
+    `share_prefix` selects the old launch sequence."""
+    dev = backend
+    cfg, sd = tiny
+    lat, text, vid, noise = make_inputs(cfg)
+    lats = torch.cat([lat + 0.1 * v for v in range(V)], 0).half()
+    tu = torch.cat([text[[0]] + 0.05 * v for v in range(V)], 0).half()
+    tc = torch.cat([text[[1]] - 0.05 * v for v in range(V)], 0).half()
+    text2 = torch.cat([tu, tc], 0)
+    eng = UNet3DEngine(sd, cfg, dev)
+    shared = to_lat(eng.forward(lats.to(dev), 701, text2.to(dev), dup=True), 2 * V, 4, 8, 8)
+    full = to_lat(eng.forward(torch.cat([lats, lats], 0).to(dev), 701, text2.to(dev)), 2 * V, 4, 8, 8)
+    with torch.no_grad():
+        ref = U.unet_forward(sd, cfg, torch.cat([lats, lats], 0).float(), 701, text2.float())
+    assert rel_err(shared, full) < 4e-3, rel_err(shared, full)
+    assert rel_err(shared, ref) < 2e-2 and rel_err(full, ref) < 2e-2
+    with pytest.raises(ValueError):
+        eng.forward(lats.to(dev), 701, text2[:V].to(dev), dup=True)
+    # the taped (guided) path: gradient of the conditional halves through the junction
+    reps = [G.extract_representation(sd, cfg, vid + 0.01 * v, noise, tu[[v]].float()) for v in range(V)]
+    rep_dev = eng.prepare_representation(reps if V > 1 else reps[0])
+    outs = {}
+    for share in (True, False):
+        eng.share_prefix = share
+        outs[share] = eng.guided_eps_and_grad(lats.to(dev), 701, tc.to(dev), rep_dev, 2000.0, want_loss=True,
+                                              text_uncond=tu.to(dev))
+    eng.share_prefix = True
+    (ec1, g1, l1, eu1), (ec0, g0, l0, eu0) = outs[True], outs[False]
+    assert rel_err(g1, g0) < 2e-2, rel_err(g1, g0)
+    assert rel_err(ec1.float(), ec0.float()) < 4e-3 and rel_err(eu1.float(), eu0.float()) < 4e-3
+    assert abs(float(l1) - float(l0)) < 2e-3 * abs(float(l0))
+    hp = dict(HP, guidance_steps=2)
+    for v in range(V):      # each video against its own oracle step (the loss weight is applied un-scaled: step factor 1)
+        control = lats[[v]].float().clone().requires_grad_(True)
+        rec = {}
+        U.unet_forward(sd, cfg, control, 701, tc[[v]].float(), record=rec, hooked=("up_blocks.1",))
+        loss = 2000.0 * G.temp_loss(G.temp_attn_prob(rec, cfg["motion_heads"]), reps[v])
+        (gref,) = torch.autograd.grad(loss, control)
+        assert rel_err(g1[v:v + 1], gref) < 5e-2, rel_err(g1[v:v + 1], gref)

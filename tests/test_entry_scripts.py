@@ -225,3 +225,61 @@ def test_launcher_lanes_reproduce_the_serial_run(runs):
         got = np.load(os.path.join(str(work), "videos_rank0", name + ".npy"))
         assert np.array_equal(got, serial[k]), "lane %d video differs from the serial run" % k
         assert os.path.exists(os.path.join(str(work), "mr_sharded", "rank0_lane%d" % k, "clip.pt"))
+
+
+def test_eight_ranks_run_the_eight_pairs_of_config_3_bit_identical_to_the_serial_run(tmp_path):
+    """BASELINE config 3 without the hardware (round-4 verdict, item 9): the eight lines of the reference's
+    configs/t2v_camera.jsonl:1-8 - three reference videos, seeds 42, 42, 2026, default, 2026, 2026, 2026, default
+    (t2v_video_sample.py:75-105) - through `motionclone_amd.launch` under an EIGHT-rank gloo job, one line per rank, on the host
+    simulator; every video is bit-identical to the single-process run of the unmodified script over all eight lines (the
+    launcher burns the skipped examples' draws from the global generator, quirk 10), every line ran exactly once, and
+    rank 0 alone read the checkpoint files."""
+    import json as _json
+    import socket
+    import entry_harness as EH
+    work = str(tmp_path)
+    env0 = dict(os.environ, PYTHONPATH=ROOT)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env0.pop(k, None)
+    serial = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), "t2v", work, "--camera8"],
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env0, cwd=work)
+    # the sharded job needs the assets the serial child writes first (checkpoints, configs, the examples file)
+    import time
+    t0 = time.time()
+    while not os.path.exists(os.path.join(work, "examples.jsonl")):
+        assert serial.poll() is None and time.time() - t0 < 600, "the serial run did not write its assets"
+        time.sleep(0.5)
+    time.sleep(1.0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(8):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="8", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   OMP_NUM_THREADS="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "entry_harness.py"), "t2v", work, "--launch"],
+                                      stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=env, cwd=work))
+    out_serial = serial.communicate(timeout=2400)[0]
+    assert serial.returncode == 0 and "ENTRY_OK" in out_serial, out_serial[-4000:]
+    outs = [p.communicate(timeout=2400)[0] for p in procs]
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0 and "ENTRY_OK" in o, o[-4000:]
+    assert '"world": 8' in outs[0] and '"examples": 8' in outs[0]
+    r0 = [_json.loads(ln) for ln in outs[0].splitlines() if ln.startswith('{"examples"')][0]
+    for r in range(1, 8):
+        rr = [_json.loads(ln) for ln in outs[r].splitlines() if ln.startswith('{"rank": %d' % r)][0]
+        assert rr["checkpoint_files_read_from_disk"] == 0 and rr["received_by_broadcast"] == r0["checkpoint_files_read_by_rank0"] >= 3
+    rec = torch.load(os.path.join(work, "record.pt"))
+    want = ["%s_%s%d_%d.mp4" % (stem, prompt.replace(" ", "_"), seed or 2025, seed or 2025) for stem, prompt, seed in EH.CAMERA8]
+    assert [os.path.basename(v) for v in rec["videos"]] == want
+    seen = set()
+    for r in range(8):
+        mine = sorted(os.listdir(os.path.join(work, "videos_rank%d" % r)))
+        assert mine == [want[r] + ".npy"], (r, mine)          # line r -> rank r, and nothing else
+        got = np.load(os.path.join(work, "videos_rank%d" % r, mine[0]))
+        assert np.array_equal(got, np.load(rec["videos"][r] + ".npy")), "rank %d: video differs from the serial run" % r
+        seen.add(mine[0])
+    assert len(seen) == 8
+    # different seeds / prompts / reference videos really gave different videos (the comparison above is not vacuous)
+    vids = [np.load(v + ".npy") for v in rec["videos"]]
+    assert not np.array_equal(vids[0], vids[1]) and not np.array_equal(vids[3], vids[7])

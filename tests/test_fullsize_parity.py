@@ -15,9 +15,14 @@ convolutions use PyTorch's im2col + GEMM path, see parity_util.oracle_mode).
                        guidance seed at (F = 32, d = 160)), plain and last step
 
 Weights: synthetic seed 1234 with motion proj_out re-randomised; both sides use the same fp16-rounded
-parameters.  Tolerances (parity_util, 3-4x the measured errors): forward / latents 5e-3 relative L2, gradient 2e-2, loss 0.2 %,
-arg-max flips must be ties (oracle gap <= 5e-4), at most 0.5 % of the rows, and are counted exactly.  Measured errors are
-written to gpurun_out/parity_r04.json.
+parameters.  Tolerances (parity_util, 3-4x the measured errors): forward / latents 5e-3 relative L2, loss 0.2 %, arg-max flips
+must be ties (oracle gap <= 5e-4), at most 0.5 % of the rows, and are counted exactly; round 5: guidance gradient 1.2e-2
+(1.5e-2 at config 5's real size) = 2x the measured errors.  Measured errors are written to gpurun_out/parity_r05.json.
+
+Round 5 additions: the fp16 oracle (the reference's arithmetic through stock PyTorch) as second witness for the guidance
+LOSS, GRADIENT and the whole 30-step config-2 trajectory (reported next to the engine's distance from the fp32 oracle);
+config 4 over ALL 30 steps; the top-1 / probability kernels against the reference's own fp16 torch ops on the GPU, fed with
+the q / k the engine recorded at config 2 and config 5 size (bit-equal away from fp16 rounding boundaries).
 """
 import pytest
 import torch
@@ -60,7 +65,8 @@ def test_forward_extraction_guided_plain(world, shape, sched):
     smp = sampler(eng, *sched)
     PU.check_forward_b2(eng, sdo, cfg, lat, text, int(smp.timesteps[0]), key)
     _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
-    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, tol_grad=PU.TOL_GRAD_FULLSIZE,
+                                  witness_sd16=PU.fp16_weights(sd))
     nxt2, _ = PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
     PU.check_plain_step(eng, smp, sdo, cfg, nxt2, text, smp.N - 1, key)      # last step: alpha_prev = final_alpha_cumprod
     torch.cuda.empty_cache()
@@ -88,14 +94,15 @@ def test_full_loop_config2(world):
     smp = sampler(eng, 30, 18, 0.4)
     with PU.oracle_mode(dev):
         rep_ref = G.extract_representation(sdo, cfg, vid.float(), noise.float(), text[0:1].float())
-    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg2_full_loop", tol=5e-3)   # measured 6.0e-4 -> 1.5e-3
+    # measured 6.0e-4 -> 1.5e-3; round 5: the reference's own fp16 arithmetic follows as a third trajectory (witness)
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg2_full_loop", tol=5e-3, witness_sd16=PU.fp16_weights(sd))
     torch.cuda.empty_cache()
 
 
-def test_trajectory_config4_sparsectrl_across_the_switch(world):
-    """BASELINE config 4 (i2v_rgb + SparseCtrl, schedule (30, 12, 0.3)): 8 CONSECUTIVE steps 8 .. 15 - four guided steps with
-    the cool-down active and four plain ones - the SparseCtrl encoder re-run on every step's timestep on both sides, engine
-    and oracle each on their own trajectory from a common latent."""
+def test_full_loop_config4_sparsectrl(world):
+    """BASELINE config 4 (i2v_rgb + SparseCtrl, schedule (30, 12, 0.3)): ALL 30 steps (round 4: steps 8 .. 15) - 12 guided
+    with warm-up and cool-down, the switch, 18 plain, the last step - the SparseCtrl encoder re-run on every step's timestep
+    on both sides, engine and oracle each on their own trajectory from the seeded initial latent."""
     dev, cfg, sd, eng, sdo = world
     F, H, W = 16, 64, 64
     csd = spec.synthetic_controlnet_state_dict(cfg, seed=4321, device=dev)
@@ -116,7 +123,7 @@ def test_trajectory_config4_sparsectrl_across_the_switch(world):
                        mid_residual=mr)
         rep_ref = G.motion_representation(G.temp_attn_prob(rec, cfg["motion_heads"]))
     del dr, mr, rec
-    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg4_trajectory", tol=4e-3, first=8, last=16, ctrl=ctrl, csdo=csdo)
+    PU.check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, "cfg4_full_loop", tol=5e-3, ctrl=ctrl, csdo=csdo)
     torch.cuda.empty_cache()
 
 
@@ -132,7 +139,7 @@ def test_32_frames_forward_extraction_guided_plain(world, hw):
     smp = sampler(eng, 50, 30, 0.4)
     PU.check_forward_b2(eng, sdo, cfg, lat, text, int(smp.timesteps[0]), key)
     _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
-    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, tol_grad=PU.TOL_GRAD_FULLSIZE)
     nxt2, _ = PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
     PU.check_plain_step(eng, smp, sdo, cfg, nxt2, text, smp.N - 1, key)
     torch.cuda.empty_cache()
@@ -168,7 +175,7 @@ def test_config5_32_frames_768_forward_extraction_guided_plain(world):
     torch.cuda.empty_cache()
     _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
     torch.cuda.empty_cache()
-    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, tol_grad=PU.TOL_GRAD_CONFIG5)
     torch.cuda.empty_cache()
     nxt2, _ = PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
     PU.check_plain_step(eng, smp, sdo, cfg, nxt2, text, smp.N - 1, key)
@@ -209,7 +216,8 @@ def test_sparsectrl_config4(world):
     _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key, ctrl=ctrl, res=(dr, mr))
     res_u = ([d[[0]] for d in d_ref], m_ref[[0]])
     res_c = ([d[[1]] for d in d_ref], m_ref[[1]])
-    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, ctrl=ctrl, res_u=res_u, res_c=res_c)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, ctrl=ctrl, res_u=res_u, res_c=res_c,
+                                  tol_grad=PU.TOL_GRAD_FULLSIZE)
     tG = int(smp.timesteps[smp.G])
     with torch.no_grad(), PU.oracle_mode(dev):
         d3, m3 = U.controlnet_forward(csdo, cfg, (2, 4, F, H, W), tG, text.float(), cond.float(), mask.float(), scale)
@@ -252,4 +260,83 @@ def test_fp16_oracle_second_witness(world):
         n, tot, gap, _ = PU.flip_stats(rep16[k][1], rep16[k][0], p32[k])
         flips, total = flips + n, total + tot
     PU.report(key, witness_fp16_oracle_extraction_flips=flips, witness_rows=total)
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 64), (32, 96, 96)], ids=["cfg2", "cfg5"])
+def test_top1_and_prob_equal_the_reference_fp16_torch_ops_on_the_engines_own_qk(world, shape):
+    """Index work end to end (round-4 verdict, weak 2): the q / k the ENGINE records in its extraction forward at config 2 and
+    config 5 size go (a) through mc_tattn_top1_f16 / mc_tattn_prob_f16 and (b) through the reference's own fp16 torch ops ON
+    THE GPU - reshape_heads_to_batch_dim (attention.py:367-372), get_attention_scores = baddbmm(beta 0, alpha scale) ->
+    softmax(-1) -> .to(fp16) (attention.py:564-611), reshape (motionclone_functions.py:279), topk(k=1) + uint8 (:79).
+    The uint8 indices, the fp16 top values and the whole fp16 probability tensor must be EQUAL, except on rows an exact (fp64)
+    evaluation marks ambiguous: a score within the fp32 dot-product error of an fp16 rounding boundary, or a probability
+    within 2e-6 relative of one - there the reference's own result depends on its GEMM's summation order.  Counted and
+    reported; fewer than 1 % of the rows may be ambiguous-and-different (measured 0.28 % at config 2, 0.58 % at config 5), and
+    on those rows the two fp16 probability tensors stay within one score rounding of each other (< 2 % relative)."""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = shape
+    key = "cfg2_16f_512" if F == 16 else "cfg5_32f_768"
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 30, 18, 0.4)
+    noisy = smp.add_noise(400, vid, noise)
+    record = {}
+    eng.forward(noisy, 400, text[0:1], record=record, only_motion_feature=True)
+    from motionclone_amd import ops
+    rows = differ = amb_rows = unexplained = ties = idx_differs = 0
+    worst_rel = 0.0
+    for name in eng.hooked_names():
+        r = record[name]
+        C, g, heads, d = r["C"], r["geo"], r["heads"], r["d"]
+        q_tok, k_tok = r["qkv"][:, :C], r["qkv"][:, C:2 * C]
+        val, idx = ops.tattn_top1(q_tok, k_tok, g.B, g.F, g.hw, heads, d)
+        prob = ops.tattn_prob(q_tok, k_tok, g.B, g.F, g.hw, heads, d)
+
+        def seq(t):      # token matrix [(b f n), C] -> the processor's [(b n), f, C] (motion_module.py:279)
+            return t.reshape(g.B, g.F, g.hw, C).permute(0, 2, 1, 3).reshape(g.B * g.hw, g.F, C).contiguous()
+
+        def heads_to_batch(t):   # attention.py:367-372
+            b, s_, dim = t.shape
+            return t.reshape(b, s_, heads, dim // heads).permute(0, 2, 1, 3).reshape(b * heads, s_, dim // heads).contiguous()
+        qh, kh = heads_to_batch(seq(q_tok)), heads_to_batch(seq(k_tok))
+        scale = d ** -0.5
+        scores = torch.baddbmm(torch.empty(qh.shape[0], qh.shape[1], kh.shape[1], dtype=qh.dtype, device=dev), qh,
+                               kh.transpose(-1, -2), beta=0, alpha=scale)
+        p_ref = scores.softmax(dim=-1).to(qh.dtype).reshape(-1, heads, g.F, g.F)
+        v_ref, i_ref = torch.topk(p_ref, k=1, dim=-1)
+        i_ref = i_ref.to(torch.uint8)
+        # exact evaluation of the reference's order of operations
+        q64, k64 = qh.double(), kh.double()
+        sc = float(torch.tensor(scale, dtype=torch.float32))
+        s64 = (q64 @ k64.transpose(-1, -2)) * sc
+        mag = (q64.abs() @ k64.abs().transpose(-1, -2)) * sc
+
+        def near(x, tol):
+            return (x + tol).half() != (x - tol).half()
+        p64 = torch.softmax(s64.half().double(), dim=-1)
+        amb = (near(s64, 1e-6 * mag) | near(p64, 2e-6 * p64)).any(-1).reshape(-1, heads, g.F)
+        # equal fp16 maxima in a row: the kernel takes the lowest index (what the CPU topk does); the device topk may return any
+        # of them, so on such rows the kernel's index only has to point at one of the maxima
+        tie = (p_ref == v_ref).sum(-1) > 1
+        at_idx = torch.gather(p_ref, -1, idx.long())
+        idx_ok = (idx[..., 0] == i_ref[..., 0]) | (tie & (at_idx[..., 0] == v_ref[..., 0]))
+        bad = ~idx_ok | (val[..., 0] != v_ref[..., 0]) | (prob != p_ref).any(-1)
+        ties += int(tie.sum())
+        idx_differs += int((~idx_ok).sum())
+        # where the fp16 tensors are not bit-equal they are one score-rounding apart: an fp16 score off by one ulp (<= 2^-11 of
+        # |s| <= ~8) moves a probability by <= ~0.4 %
+        dp = ((prob.float() - p_ref.float()).abs() / p_ref.float().clamp_min(1e-4)).amax(-1)
+        worst_rel = max(worst_rel, float(dp[bad].max()) if bad.any() else 0.0)
+        rows += bad.numel()
+        differ += int(bad.sum())
+        amb_rows += int(amb.sum())
+        unexplained += int((bad & ~amb).sum())
+        del scores, p_ref, s64, mag, p64, q64, k64
+    PU.report(key, top1_vs_reference_fp16_torch_rows=rows, top1_vs_reference_fp16_torch_rows_differing=differ,
+              top1_rows_on_a_rounding_boundary=amb_rows, top1_rows_differing_off_boundary=unexplained,
+              top1_rows_with_equal_fp16_maxima=ties, top1_rows_with_another_index=idx_differs,
+              top1_differing_rows_max_rel_prob_difference=worst_rel)
+    assert unexplained == 0, "%d rows differ from the reference's fp16 torch path away from any rounding boundary" % unexplained
+    assert differ <= 0.01 * rows, (differ, rows)
+    assert worst_rel < 2e-2, worst_rel
     torch.cuda.empty_cache()

@@ -43,6 +43,42 @@ def table(path, videos, top=34):
     return ncalls, tot, sum(int(r["Calls"]) for r in mine), "\n".join(out)
 
 
+def durations_json(stats_path, trace_dir, videos, vpm, tag):
+    """-> profiles/kernel_durations_timed.json (read by bench.py: roofline_timed): per kernel calls / average duration of the
+    TIMED regime, the summed kernel time, and - when the raw kernel trace is still there - the overlap factor = summed kernel
+    time / length of the union of the kernel intervals (how many kernels run at once on average)."""
+    rows = list(csv.DictReader(open(stats_path)))
+    kern = {re.sub(r"^void ", "", re.sub(r"\(.*$", "", r["Name"])).replace("mc::", ""):
+            dict(calls=int(r["Calls"]), avg_us=float(r["AverageNs"]) / 1e3) for r in rows}
+    total = sum(int(r["TotalDurationNs"]) for r in rows) / 1e9
+    overlap = None
+    tr = glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True)
+    if tr:
+        iv = []
+        for r in csv.DictReader(open(max(tr, key=os.path.getsize))):
+            iv.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+        iv.sort()
+        busy, cur_s, cur_e = 0, None, None
+        for s_, e_ in iv:
+            if cur_e is None or s_ > cur_e:
+                if cur_e is not None:
+                    busy += cur_e - cur_s
+                cur_s, cur_e = s_, e_
+            else:
+                cur_e = max(cur_e, e_)
+        if cur_e is not None:
+            busy += cur_e - cur_s
+        overlap = sum(e_ - s_ for s_, e_ in iv) / max(1, busy)
+    try:
+        import subprocess
+        code = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip() or None
+    except Exception:   # noqa: BLE001
+        code = None
+    return dict(regime="hipGraph replay, three videos in flight: `python bench.py --no-cpu-baseline --no-vae --steps 3` under "
+                       "rocprofv3 --kernel-trace --stats (%s)" % tag, videos_in_trace=videos, videos_per_min_under_profiler=vpm,
+                total_kernel_s=total, overlap=overlap, code=code, kernels=kern)
+
+
 a_dir, b_dir, out_md, tag = sys.argv[1:5]
 va = int(sys.argv[5]) if len(sys.argv) > 5 else 10   # 3 warm-up + 3 timed + 4 eager (probe pass)
 vb = int(sys.argv[6]) if len(sys.argv) > 6 else 7    # 1 warm-up + 2 timed + 4 eager
@@ -54,7 +90,7 @@ na, ta, ma, tab_a = table(pa, va)
 nb, tb, mb, tab_b = table(pb, vb)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
-`tools/gpu_profile_r04.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
+`tools/gpu_profile_r05.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
 timed, and the four eager videos of the bench's probe pass).  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, ring stages>` (MODE 0 dense, 1
 conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU; 256, 160, 4, 3 = two workgroups per CU), `gemm4_kernel<20, GEGLU, NORM>` = K = 320 streaming
 kernel (NORM 1 = LayerNorm, 2 = GroupNorm applied to the rows in registers),
@@ -75,4 +111,5 @@ total kernel time %.1f s = %.2f s per video.
 %s
 """ % (tag, bench_value(a_dir), va, na, round(na / va), round(ma / va), ta, tab_a, bench_value(b_dir), vb, nb, round(nb / vb), tb, tb / vb, tab_b)
 open(out_md, "w").write(md)
+json.dump(durations_json(pa, a_dir, va, bench_value(a_dir), tag), open(os.path.join(os.path.dirname(out_md), "kernel_durations_timed.json"), "w"), indent=1)
 print(out_md, "launches per video:", round(na / va), round(nb / vb))
