@@ -370,6 +370,10 @@ def main():
                     "K = 320 GEMMs (the round-3 launch sequence) instead of mc_norm_gemm_f16")
     ap.add_argument("--no-shared-prefix", action="store_true", help="A/B: feed the UNet the duplicated CFG batch [x | x] as rounds 1-4 did, "
                     "instead of running what precedes the first cross-attention once for both halves (engine.forward: dup)")
+    ap.add_argument("--two-b1-guided", action="store_true", help="A/B: guided steps as the reference issues them - eps_u and eps_c as two "
+                    "B = 1 forwards (the un-guided one keeps nothing for a backward) instead of one B = 2 forward")
+    ap.add_argument("--no-probe", action="store_true", help="skip the eager / roofline-probe videos after the timed region (profiling "
+                    "runs that should hold the timed regime's kernels only: tools/gpu_profile_r05.sh)")
     ap.add_argument("--probe-one-lane", action="store_true", help="roofline probe video with the tile choice of ONE video in flight "
                     "(round 4's probe regime) instead of the timed region's")
     ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r05_bench_detail.json")
@@ -425,7 +429,8 @@ def main():
         from motionclone_amd.engine import ControlNetEngine
         ceng = ControlNetEngine(spec.synthetic_controlnet_state_dict(cfg, seed=4321, device=dev), cfg, dev)
     smp = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
-                             num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng)
+                             num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng,
+                             batch_guided=not args.two_b1_guided)
     # per-rank example seeds as in configs/t2v_camera.jsonl (42, 42, 2026, default 2025, ...)
     seeds = [42, 42, 2026, 2025, 2026, 2026, 2026, 2025]
     lat, text, vid, noise = synth_inputs(dev, args.frames, args.size, args.size, seeds[rank % len(seeds)])
@@ -455,7 +460,7 @@ def main():
     streams = [torch.cuda.Stream(device=dev) for _ in range(NF)]
     smps = [smp] + [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                                        num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE,
-                                       controlnet=ceng) for _ in range(NF - 1)]
+                                       controlnet=ceng, batch_guided=not args.two_b1_guided) for _ in range(NF - 1)]
     if use_graphs:
         for sm in smps:
             sm.enable_graphs()
@@ -519,9 +524,10 @@ def main():
     # inside a graph replay.  `eager` also reports what the un-graphed loop costs on this box.
     eager_info = None
     probe_elapsed = None
-    if rank == 0:
+    if rank == 0 and not args.no_probe:
         sme = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
-                                 num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng)
+                                 num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng,
+                                 batch_guided=not args.two_b1_guided)
         def eager_lane0():     # lane 0's job (one video, or its --batch videos as one launch sequence) without graphs
             if VB == 1:
                 return one_video(sme, lat, text, vid, noise, ctrl=ctrl)
@@ -563,8 +569,8 @@ def main():
         table = {(16, 256): (10.41, 8.17, 2.39), (16, 512): (45.50, 35.35, 10.06), (32, 768): (235.9, 181.1, 49.7)}
         tg, tp, te = table.get((args.frames, args.size), (float("nan"),) * 3)
         tflop_video = G_STEPS * tg + (N_STEPS - G_STEPS) * tp + te
-        roof_all = probe.summary(probe_elapsed)
-        by_shape = probe.by_shape()
+        roof_all = probe.summary(probe_elapsed) if probe_elapsed else {}
+        by_shape = probe.by_shape() if probe_elapsed else []
         if args.shapes_out:
             json.dump(by_shape, open(args.shapes_out, "w"), indent=1)
         # HBM bytes per launch from rocprofv3 PMC passes (FETCH_SIZE x 2 + WRITE_SIZE, MI355X_MICROARCH.md), per SHAPE, next to
@@ -636,7 +642,7 @@ def main():
                              "regime (graphs, videos in flight) from the committed rocprofv3 kernel trace of this command "
                              "(profiles/kernel_durations_timed.json, profiles/r05_kernel_stats.md)",
             "roofline_by_kernel": roof_all,
-            "roofline_coverage_of_probe_video": probe.covered(probe_elapsed),
+            "roofline_coverage_of_probe_video": probe.covered(probe_elapsed) if probe_elapsed else None,
             "roofline_traffic_by_shape": traffic_rows,
             "hbm_footprint": hbm,
             # SURVEY.md 8(f) rank 1, measured OUTSIDE the timed region (BASELINE's metric is the UNet loop): the VAE calls
@@ -669,6 +675,7 @@ def main():
         sys.stdout.flush()
         print(compact_line(res, detail), flush=True)
     if dist is not None:
+        dist.barrier()      # rank 0 runs its probe / eager videos after the timed region: the ranks leave together
         dist.destroy_process_group()
 
 

@@ -32,7 +32,11 @@ namespace mc {
 //           motion_module.py:204,210,237-246; (mean, rstd) optionally written for the backward.  The variance is
 //           E[x^2] - mean^2 from fp32 sums (ln_fwd5_kernel and torch subtract the mean first): relative error ~1e-7 (1 +
 //           mean^2 / var), i.e. it reaches the fp16 resolution of the output only for rows whose |mean| exceeds ~100 standard
-//           deviations - GroupNorm's statistics (gn_finalize / gn_block_stats) have always been computed this way;
+//           deviations - GroupNorm's statistics (gn_finalize / gn_block_stats) have always been computed this way.  A second
+//           pass over the register-resident fragments on (x - mean) (round-4 advice) would have to subtract in fp16 (the
+//           fragments are the MFMA operands): each difference then carries up to 2^-11 of ITS size, a relative variance error
+//           of ~1e-4 .. 5e-4 - worse than the one-pass fp32 formula for every row with |mean| < ~60 standard deviations; the
+//           16-sigma test (tests/test_kernels.py) is where the two would still be ~30x apart in favour of this one;
 //   kind 2  GroupNorm WITHOUT activation (Transformer3DModel.norm / TemporalTransformer3DModel.norm, eps 1e-6): per frame an
 //           affine map x sc[k] + sh[k] (sc = rstd gamma, sh = beta - mean sc; the arithmetic of gn_apply_kernel); the
 //           statistics are finalised from the per-chunk partial sums in the prologue (gn_block_stats) and written for the

@@ -142,8 +142,8 @@ class Tape:
 
     def __init__(self, grad_batch=None):
         self.fns = []
-        self.grads = {}
-        self.keep = []
+        self.grads = {}                # id(activation) -> gradient
+        self.alive = {}                # id(activation) -> activation, while its gradient is pending
         # differentiate only these batch elements of a B > 1 forward: an index b, or a range (b0, b1) = elements b0 .. b1 - 1
         # (the conditional halves of several videos batched as [u_1 .. u_V | c_1 .. c_V]); None: all
         self.grad_batch = grad_batch
@@ -160,15 +160,21 @@ class Tape:
             ops.add(g, dx, out=g)
         else:
             self.grads[key] = dx
-            self.keep.append(x)
+            self.alive[key] = x            # held until its gradient is taken: id(x) stays unique meanwhile
 
     def take(self, x):
+        self.alive.pop(id(x), None)
         return self.grads.pop(id(x), None)
 
     def run(self):
-        for fn in reversed(self.fns):
+        """closures run in reverse order and are DROPPED as they finish: the activations a block saved for its backward are
+        released (to the graph's memory pool, for the blocks still to come) as soon as that block is done, instead of
+        staying alive until the whole backward has run (round 5)"""
+        fns, self.fns = self.fns, []
+        while fns:
+            fn = fns.pop()
             fn()
-        self.fns = []
+            del fn
 
     def whole_batch(self):
         """the same tape for modules whose forward ran on the differentiated batch elements ONLY (the shared prefix of a

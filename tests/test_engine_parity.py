@@ -313,16 +313,14 @@ def test_shared_prefix_of_the_cfg_batch_equals_the_duplicated_batch(backend, tin
     # the taped (guided) path: gradient of the conditional halves through the junction
     reps = [G.extract_representation(sd, cfg, vid + 0.01 * v, noise, tu[[v]].float()) for v in range(V)]
     rep_dev = eng.prepare_representation(reps if V > 1 else reps[0])
-    outs = {}
-    for share in (True, False):
-        eng.share_prefix = share
-        outs[share] = eng.guided_eps_and_grad(lats.to(dev), 701, tc.to(dev), rep_dev, 2000.0, want_loss=True,
-                                              text_uncond=tu.to(dev))
-    eng.share_prefix = True
-    (ec1, g1, l1, eu1), (ec0, g0, l0, eu0) = outs[True], outs[False]
-    assert rel_err(g1, g0) < 2e-2, rel_err(g1, g0)
-    assert rel_err(ec1.float(), ec0.float()) < 4e-3 and rel_err(eu1.float(), eu0.float()) < 4e-3
-    assert abs(float(l1) - float(l0)) < 2e-3 * abs(float(l0))
+    ec1, g1, l1, eu1 = eng.guided_eps_and_grad(lats.to(dev), 701, tc.to(dev), rep_dev, 2000.0, want_loss=True, text_uncond=tu.to(dev))
+    if V == 1:      # (one A/B on the host simulator is enough: the switch only selects the launch sequence)
+        eng.share_prefix = False
+        ec0, g0, l0, eu0 = eng.guided_eps_and_grad(lats.to(dev), 701, tc.to(dev), rep_dev, 2000.0, want_loss=True, text_uncond=tu.to(dev))
+        eng.share_prefix = True
+        assert rel_err(g1, g0) < 2e-2, rel_err(g1, g0)
+        assert rel_err(ec1.float(), ec0.float()) < 4e-3 and rel_err(eu1.float(), eu0.float()) < 4e-3
+        assert abs(float(l1) - float(l0)) < 2e-3 * abs(float(l0))
     hp = dict(HP, guidance_steps=2)
     for v in range(V):      # each video against its own oracle step (the loss weight is applied un-scaled: step factor 1)
         control = lats[[v]].float().clone().requires_grad_(True)

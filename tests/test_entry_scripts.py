@@ -237,6 +237,8 @@ def test_eight_ranks_run_the_eight_pairs_of_config_3_bit_identical_to_the_serial
     import json as _json
     import socket
     import entry_harness as EH
+    from motionclone_amd import build
+    build.build_emu()          # once, here: nine children would otherwise race to rebuild a stale simulator library
     work = str(tmp_path)
     env0 = dict(os.environ, PYTHONPATH=ROOT)
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
@@ -274,7 +276,7 @@ def test_eight_ranks_run_the_eight_pairs_of_config_3_bit_identical_to_the_serial
     assert [os.path.basename(v) for v in rec["videos"]] == want
     seen = set()
     for r in range(8):
-        mine = sorted(os.listdir(os.path.join(work, "videos_rank%d" % r)))
+        mine = sorted(f for f in os.listdir(os.path.join(work, "videos_rank%d" % r)) if f.endswith(".npy"))
         assert mine == [want[r] + ".npy"], (r, mine)          # line r -> rank r, and nothing else
         got = np.load(os.path.join(work, "videos_rank%d" % r, mine[0]))
         assert np.array_equal(got, np.load(rec["videos"][r] + ".npy")), "rank %d: video differs from the serial run" % r
