@@ -9,9 +9,6 @@ T=${1:-r05}
 mkdir -p gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b
 timeout 1500 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/${T}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/${T}_pytest_gpu.log
 timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 2
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_final.log 2> gpurun_out/${T}_bench_final.err
-echo "driver-like bench rc=$?"; grep '^{' gpurun_out/${T}_bench_final.log | tail -n 1 > gpurun_out/${T}_bench_final_line.json; cut -c1-1800 gpurun_out/${T}_bench_final_line.json; echo
-cp gpurun_out/r05_bench_detail.json gpurun_out/${T}_bench_final_detail.json
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_a -- python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --steps 6 --warmup 3 > gpurun_out/prof_${T}_a/bench.json 2> gpurun_out/prof_${T}_a/bench.err
 echo "trace a rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_b -- python bench.py --no-cpu-baseline --no-vae --no-detail --no-graphs --inflight 1 --steps 2 > gpurun_out/prof_${T}_b/bench.json 2> gpurun_out/prof_${T}_b/bench.err
@@ -20,6 +17,10 @@ python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gp
 find gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b -name "*kernel_trace.csv" -delete
 python -c "
 import json; d=json.load(open('gpurun_out/kernel_durations_timed.json')); print('timed durations:', len(d['kernels']), 'kernels, total', round(d['total_kernel_s'],2), 's, overlap', d['overlap'])"
+cp gpurun_out/kernel_durations_timed.json profiles/kernel_durations_timed.json    # what the bench line's roofline_timed reads (same box, same code)
+timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_final.log 2> gpurun_out/${T}_bench_final.err
+echo "driver-like bench rc=$?"; grep '^{' gpurun_out/${T}_bench_final.log | tail -n 1 > gpurun_out/${T}_bench_final_line.json; cut -c1-1800 gpurun_out/${T}_bench_final_line.json; echo
+cp gpurun_out/r05_bench_detail.json gpurun_out/${T}_bench_final_detail.json
 # HBM traffic per shape in the tile choice of the timed region (three videos in flight)
 mkdir -p gpurun_out/pmc_${T}_l3
 for c in FETCH_SIZE WRITE_SIZE; do
