@@ -16,6 +16,7 @@ DENSE, CONV_S1, CONV_S2, CONV_UP, TCONV_S2 = 0, 1, 2, 3, 4
 class _Pinned(threading.local):
     stream = None   # HIP stream handle pinned for the duration of one engine call (see `scoped`); per host thread, like
                     # torch's current stream, so engines driven from several threads keep their own streams
+    share = None    # tile-policy override of the engine whose call is running (`gemm_lanes` attribute, see `scoped`)
 
 
 _PIN = _Pinned()
@@ -27,14 +28,21 @@ def scoped(fn):
     Evaluated when the method is entered, so a call made under hipGraph capture pins the capturing stream."""
     def wrapper(self, *a, **k):
         pin = _PIN
-        prev = pin.stream
+        prev, prev_share = pin.stream, pin.share
         dev = getattr(self, "dev", None)
         if prev is None and dev is not None and dev.type == "cuda":
             pin.stream = torch.cuda.current_stream(dev).cuda_stream
+        # an engine / sampler that sets `gemm_lanes` (the launch sequences ITS owner keeps in flight) overrides the process-wide
+        # set_gemm_share for the duration of its calls: two samplers with different lane counts can share a process
+        lanes = getattr(self, "gemm_lanes", None)
+        if lanes is None:
+            lanes = getattr(getattr(self, "engine", None), "gemm_lanes", None)
+        if lanes is not None:
+            pin.share = _share_of(lanes)
         try:
             return fn(self, *a, **k)
         finally:
-            pin.stream = prev
+            pin.stream, pin.share = prev, prev_share
     wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
     return wrapper
 
@@ -84,13 +92,23 @@ _SPLIT_PLAN = {}   # (M, N, K, mode) -> mc_gemm_splitk_plan, memoised: one ctype
 _GEMM_SHARE = 0    # log2 of the launch sequences kept in flight on separate streams (set_gemm_share)
 
 
+def _share_of(lanes):
+    return 0 if lanes <= 1 else (1 if lanes < 4 else 2)
+
+
 def set_gemm_share(lanes):
     """Tell the GEMM tile / split-K choice how many independent launch sequences share the GPU (sample_interleaved:
     one per video in flight).  A launch then only has to fill 1 / lanes of the CUs (mc_gemm_f16 flags bits 20-21).  The
-    choice changes fp32 summation order, not arithmetic: results are reproducible for a given setting."""
+    choice changes fp32 summation order, not arithmetic: results are reproducible for a given setting.  This is the
+    PROCESS-WIDE default; an engine or sampler with a `gemm_lanes` attribute overrides it for its own calls (`scoped`)."""
     global _GEMM_SHARE
-    _GEMM_SHARE = 0 if lanes <= 1 else (1 if lanes < 4 else 2)
+    _GEMM_SHARE = _share_of(lanes)
     return _GEMM_SHARE
+
+
+def gemm_share():
+    """the setting in force for the calling thread: the running engine call's override, else the process-wide default"""
+    return _GEMM_SHARE if _PIN.share is None else _PIN.share
 
 
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
@@ -119,8 +137,9 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
     if out is None:
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
+    share = gemm_share()
     flags = tile | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
-        | (0 if pad_front else 0x800) | (nsplit << 16) | (_GEMM_SHARE << 20) | (0x1000000 if g3_splitk else 0)
+        | (0 if pad_front else 0x800) | (nsplit << 16) | (share << 20) | (0x1000000 if g3_splitk else 0)
     if bias is not None:
         _f32(bias)
         assert bias.shape[-1] == N
@@ -128,10 +147,10 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         if geglu or tile or deep or cfg:
             splits = 1
         else:
-            key = (M, N, K, mode, _GEMM_SHARE, lib.is_emulated())
+            key = (M, N, K, mode, share, lib.is_emulated())
             splits = _SPLIT_PLAN.get(key)
             if splits is None:
-                splits = _SPLIT_PLAN[key] = lib.load().mc_gemm_splitk_plan(M, N, K, mode | (_GEMM_SHARE << 8))
+                splits = _SPLIT_PLAN[key] = lib.load().mc_gemm_splitk_plan(M, N, K, mode | (share << 8))
             if splits > 1:      # plan = K ranges | (gemm3 geometry << 8)
                 flags |= (splits >> 8) << 12
                 splits &= 0xFF

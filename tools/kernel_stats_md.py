@@ -74,8 +74,8 @@ def durations_json(stats_path, trace_dir, videos, vpm, tag):
         code = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip() or None
     except Exception:   # noqa: BLE001
         code = None
-    return dict(regime="hipGraph replay, three videos in flight: `python bench.py --no-cpu-baseline --no-vae --steps 3` under "
-                       "rocprofv3 --kernel-trace --stats (%s)" % tag, videos_in_trace=videos, videos_per_min_under_profiler=vpm,
+    return dict(regime="hipGraph replay, three videos in flight, no probe videos: `python bench.py --no-cpu-baseline --no-vae "
+                       "--no-probe --steps 6 --warmup 3` under rocprofv3 --kernel-trace --stats (%s)" % tag, videos_in_trace=videos, videos_per_min_under_profiler=vpm,
                 total_kernel_s=total, overlap=overlap, code=code, kernels=kern)
 
 
@@ -90,22 +90,24 @@ na, ta, ma, tab_a = table(pa, va)
 nb, tb, mb, tab_b = table(pb, vb)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
-`tools/gpu_profile_r05.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace (warm-up,
-timed, and the four eager videos of the bench's probe pass).  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, ring stages>` (MODE 0 dense, 1
+`tools/gpu_profile_r05.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace: (a) warm-up +
+timed videos only (`--no-probe`: the trace holds the timed regime's kernels and nothing else; it is what
+`profiles/kernel_durations_timed.json` / the bench line's `roofline_timed` are made of), (b) warm-up, timed and the eager videos of
+the bench's probe pass.  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, ring stages>` (MODE 0 dense, 1
 conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU; 256, 160, 4, 3 = two workgroups per CU), `gemm4_kernel<20, GEGLU, NORM>` = K = 320 streaming
 kernel (NORM 1 = LayerNorm, 2 = GroupNorm applied to the rows in registers),
 `attn_*_ring_kernel<DT, rows/16 per wave>` = the LDS-DMA ring attention (DT 3: d = 40, 5: d = 80).
 
-## (a) DEFAULT command `python bench.py --no-cpu-baseline --no-vae --steps 3`: hipGraph replay, three videos in flight (kernel durations are measured while kernels of the other two videos share the CUs)
+## (a) `python bench.py --no-cpu-baseline --no-vae --no-probe --steps 6 --warmup 3`: hipGraph replay, three videos in flight (kernel durations are measured while kernels of the other two videos share the CUs)
 
-Bench line of this run: **%s videos/min** (under the profiler); videos in the trace: 3 warm-up + 3 timed + 4 eager = **%d**; %d kernel launches
+Bench line of this run: **%s videos/min** (under the profiler); videos in the trace: 3 warm-up + 6 timed = **%d**; %d kernel launches
 = **%d per video** (%d of them this library's); total kernel time %.1f s.
 
 %s
 
 ## (b) `--no-graphs --inflight 1 --steps 2`: one video at a time on the eager launch sequence (the regime of the roofline probe of bench.py)
 
-Bench line of this run: **%s videos/min**; videos in the trace: 1 warm-up + 2 timed + 4 eager = **%d**; %d kernel launches = **%d per video**;
+Bench line of this run: **%s videos/min**; videos in the trace: 1 warm-up + 2 timed + 3 eager (warm-up, timed, probe) = **%d**; %d kernel launches = **%d per video**;
 total kernel time %.1f s = %.2f s per video.
 
 %s
