@@ -273,7 +273,8 @@ def test_top1_and_prob_equal_the_reference_fp16_torch_ops_on_the_engines_own_qk(
     evaluation marks ambiguous: a score within the fp32 dot-product error of an fp16 rounding boundary, or a probability
     within 2e-6 relative of one - there the reference's own result depends on its GEMM's summation order.  Counted and
     reported; fewer than 1 % of the rows may be ambiguous-and-different (measured 0.28 % at config 2, 0.58 % at config 5), and
-    on those rows the two fp16 probability tensors stay within one score rounding of each other (< 2 % relative)."""
+    on those rows the two fp16 probability tensors stay within one score rounding of each other (measured <= 0.18 % relative,
+    bound 0.5 %); the uint8 INDICES were equal on every row of both sizes."""
     dev, cfg, sd, eng, sdo = world
     F, H, W = shape
     key = "cfg2_16f_512" if F == 16 else "cfg5_32f_768"
@@ -338,5 +339,6 @@ def test_top1_and_prob_equal_the_reference_fp16_torch_ops_on_the_engines_own_qk(
               top1_differing_rows_max_rel_prob_difference=worst_rel)
     assert unexplained == 0, "%d rows differ from the reference's fp16 torch path away from any rounding boundary" % unexplained
     assert differ <= 0.01 * rows, (differ, rows)
-    assert worst_rel < 2e-2, worst_rel
+    assert worst_rel < 5e-3, worst_rel          # measured 1.2e-3 (config 2) / 1.8e-3 (config 5): one or two fp16 ulps
+    assert idx_differs <= 1e-4 * rows, (idx_differs, rows)   # measured: 0 of 196608 and 0 of 884736 - the uint8 indices are EQUAL
     torch.cuda.empty_cache()
