@@ -23,6 +23,18 @@ if what == "twowg":
             ops.gemm(x1, wq1, cfg=cfg)                       # qkv level 1
             ops.gemm(x1, wg1, geglu=True, cfg=cfg)           # FeedForward level 1, fused GEGLU
     print("order: for cfg in (11 = 8 waves, 9 = two workgroups per CU): 2 x [to_out_l1+R, qkv_l1, ff1_l1 geglu]")
+elif what == "widen":
+    # round 5: the wide-N short-K layers where the vendor GEMM is 21 - 31 % ahead (profiles/r05_vendor_anchor.md): gemm5 on
+    # 256 x 320 tiles (cfg 11) and torch.matmul (hipBLASLt: persistent stream-K, MT 256 x 256 x 64), two launches each
+    shapes = [(32768, 5120, 640), (8192, 10240, 1280), (8192, 3840, 1280)]
+    ops_ = [(r(M, K), r(N, K, sc=0.02), torch.empty(M, N, device=dev, dtype=torch.float16)) for M, N, K in shapes]
+    torch.cuda.synchronize()
+    for x, w, o in ops_:
+        for _ in range(2):
+            ops.gemm(x, w, cfg=11, out=o)
+        for _ in range(2):
+            torch.matmul(x, w.t(), out=o)
+    print("order: for (M, N, K) in %s: 2 x gemm5 <256 x 320>, 2 x torch.matmul" % (shapes,))
 elif what == "gemm":
     F = 32
     x1, wq1, wo1, r1 = r(32768, 640), r(1920, 640, sc=0.02), r(640, 640, sc=0.02), r(32768, 640)
