@@ -100,6 +100,27 @@ def build_slp_control(force=False):
     return SLP_CONTROL_LIB
 
 
+# TEST ONLY: csrc/attention.hip with the round-5 fix of scale_in_place left out (the inline v_mul reads v_exp_f32's result one
+# cycle too early): the negative control of tests/test_kernels.py::test_attention_rebase_negative_control (never loaded by the package)
+TRANS_HAZARD_CONTROL_LIB = os.path.join(REPO, "tools", "_build", "libattn_trans_hazard.so")
+
+
+def build_trans_hazard_control(force=False):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    src = os.path.join(CSRC, "attention.hip")
+    flags = HIP_FLAGS + ["-DMC_TOOLS", "-DMC_CONTROL_TRANS_HAZARD"]
+    stamp = _stamp([src] + [d for d in _deps() if d.endswith(".hpp")], " ".join(flags))
+    stamp_file = TRANS_HAZARD_CONTROL_LIB + ".stamp"
+    if (not force and os.path.exists(TRANS_HAZARD_CONTROL_LIB) and os.path.exists(stamp_file)
+            and open(stamp_file).read() == stamp):
+        return TRANS_HAZARD_CONTROL_LIB
+    os.makedirs(os.path.dirname(TRANS_HAZARD_CONTROL_LIB), exist_ok=True)
+    _run([hipcc] + flags + ["-shared", "-o", TRANS_HAZARD_CONTROL_LIB, src])
+    with open(stamp_file, "w") as f:
+        f.write(stamp)
+    return TRANS_HAZARD_CONTROL_LIB
+
+
 def build_emu(force=False):
     """TEST ONLY: compile the same kernel sources for the host against tests/hipemu (no GPU needed)."""
     cxx = os.environ.get("MC_HOST_CXX", "/opt/rocm/lib/llvm/bin/clang++")

@@ -305,10 +305,26 @@ __device__ __forceinline__ float rows_sum(float v) {
     asm("v_add_f32 %0, %1, %2" : "=v"(m) : "v"(r[0]), "v"(r[1]));
     return m;
 }
-// x *= a in place (a tied inline v_mul): inside a rarely taken branch this keeps the untouched path free of register copies
+// x *= a in place (a tied inline v_mul): inside a rarely taken branch this keeps the untouched path free of register copies.
+// ROUND 5 BUG FIX: `a` is the result of a transcendental (v_exp_f32) at the call site, and on gfx940+ a VALU instruction that
+// reads a TRANS result needs one wait state in between (the "trans forwarding" hazard).  hipcc inserts that s_nop for its own
+// instructions but does not look inside inline asm: the FIRST v_mul of a re-base read a stale register on some lanes, i.e. element 0
+// of the first output tile of every re-based query row was scaled by whatever the register held before (the row offset): output
+// channels 0 / 4 / 8 / 12 of a head wrong by a factor of 2 - 5 whenever a row's scores outgrew their first tile's maximum by more
+// than 2^8 - never at the first key tile (the accumulators are zero there), rarely on N(0, 1) operands, on every real attention
+// map with a wide logit range.  Found by tests/test_fullsize_parity.py::test_outlier_channels_stress; regression test:
+// tests/test_kernels.py::test_attention_rows_that_outgrow_their_first_tile (GPU only: the simulator has no such hazard).  The
+// s_nop is part of the FIRST multiply's asm statement, so nothing can be scheduled between the two.
 __device__ __forceinline__ void scale_in_place(f32x4& x, float a) {
+    float e0 = x[0];
+#ifdef MC_CONTROL_TRANS_HAZARD   // TEST ONLY: the pre-fix code, built into tools/_build/libattn_trans_hazard.so as the negative control
+    asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e0) : "v"(a));
+#else
+    asm volatile("s_nop 1\n\tv_mul_f32 %0, %0, %1" : "+v"(e0) : "v"(a));
+#endif
+    x[0] = e0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 1; i < 4; ++i) {
         float e = x[i];
         asm volatile("v_mul_f32 %0, %0, %1" : "+v"(e) : "v"(a));
         x[i] = e;

@@ -449,6 +449,101 @@ def test_self_attention_long_sequence_takes_four_query_tiles_per_wave(backend):
     close(_heads(dqkv[:, 2 * C:], nb, Nq, heads, d), gv, 1e-2, 2e-2, "attn dv, 4 tiles per wave")
 
 
+@pytest.mark.parametrize("d", [40, 80])
+def test_attention_rows_that_outgrow_their_first_tile(backend, d):
+    """The ring forward keeps a per-row softmax OFFSET (not the running maximum) and re-bases it only when a score exceeds it by
+    more than 2^8 (attention.hip: kRebase).  On N(0, 1) operands that happens at the first key tile and almost never again, so
+    the re-base of a row that already HAS accumulated output was not exercised - and on the MI355X it was wrong: the rescale
+    factor comes out of v_exp_f32 and the first inline-asm v_mul read it one cycle too early (gfx940+ trans forwarding hazard,
+    mc_common.hpp: scale_in_place), corrupting element 0 of the first output tile (channels 0 / 4 / 8 / 12 of a head) by the
+    row's offset.  Here the scores of half of the rows RAMP UP along the keys by ~45 log2 units (five or six re-bases per row),
+    the other half ramp down; forward, lse and the backward (which reads the lse) against fp32 torch, and bit-stable.
+    The host simulator has no such hazard: it checks the re-base arithmetic; the GPU run is the regression test."""
+    dev = backend
+    Nq, heads, nb = (1024, 1, 1) if not big(dev) else (1024 + 128, 4, 3)
+    C = heads * d
+    g = torch.Generator().manual_seed(21)
+    u = torch.randn(heads, d, generator=g)
+    u = u / u.norm(dim=1, keepdim=True)
+    ramp = torch.linspace(0.0, 1.0, Nq)
+    amp = 45.0 / (1.4427 * d ** -0.5)                         # b = 1 rows gain 45 log2 units from the first to the last key
+    b = torch.rand(nb, Nq, heads, generator=g) * 2 - 1        # per query row: how strongly (and in which direction) it ramps
+    q = 0.7 * torch.randn(nb, Nq, heads, d, generator=g) + b[..., None] * u
+    k = 0.7 * torch.randn(nb, Nq, heads, d, generator=g) + (amp * ramp)[None, :, None, None] * u
+    v = torch.randn(nb, Nq, heads, d, generator=g)
+    q16, k16, v16 = (t.reshape(nb * Nq, C).half().to(dev) for t in (q, k, v))
+    o, lse = ops.attn_fwd(q16, k16, v16, Nq, Nq, heads, d, nb)
+    o2, lse2 = ops.attn_fwd(q16, k16, v16, Nq, Nq, heads, d, nb)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2), "the re-based rows are not bit-stable"
+    Q, K, V = (_heads(t, nb, Nq, heads, d).requires_grad_() for t in (q16, k16, v16))
+    S = (Q @ K.transpose(-1, -2)) * d ** -0.5
+    tile_max = (S.detach() * 1.4427).reshape(nb, heads, Nq, -1, 64).amax(-1) if Nq % 64 == 0 else None
+    if tile_max is not None:      # the case is what it claims to be: many rows pass their FIRST tile's maximum by > 8 later on
+        assert ((tile_max[..., 1:].amax(-1) - tile_max[..., 0]) > 8).float().mean() > 0.3
+    ref = S.softmax(-1) @ V
+    close(_heads(o, nb, Nq, heads, d), ref, 1e-2, 1e-2, "attn fwd with re-bases")
+    close(lse, torch.logsumexp(S, -1), 2e-3, 2e-3, "attn lse with re-bases")
+    do = rnd((nb * Nq, C), dev, 22)
+    gq, gk, gv = torch.autograd.grad(ref, (Q, K, V), _heads(do, nb, Nq, heads, d))
+    dq, dk, dv = ops.attn_bwd(q16, k16, v16, o, do, lse, Nq, Nq, heads, d, nb)
+    close(_heads(dq, nb, Nq, heads, d), gq, 2e-2, 2e-2, "attn dq with re-bases")
+    close(_heads(dk, nb, Nq, heads, d), gk, 2e-2, 2e-2, "attn dk with re-bases")
+    close(_heads(dv, nb, Nq, heads, d), gv, 2e-2, 2e-2, "attn dv with re-bases")
+
+
+@pytest.mark.gpu
+def test_attention_rebase_negative_control(gpu_device):
+    """The regression case above on the SHIPPED library (must be clean) and on the negative control - attention.hip built without
+    the s_nop in scale_in_place (build.build_trans_hazard_control) - whose wrong elements are counted and reported
+    (gpurun_out/attn_trans_hazard_r05.json): it shows that the ramped scores actually reach the hazard on this GPU."""
+    import ctypes
+    import json
+    import os
+    from motionclone_amd import build, lib
+    dev = gpu_device
+    d, Nq, heads, nb = 40, 1024 + 128, 4, 3
+    C = heads * d
+    g = torch.Generator().manual_seed(21)
+    u = torch.randn(heads, d, generator=g)
+    u = u / u.norm(dim=1, keepdim=True)
+    amp = 45.0 / (1.4427 * d ** -0.5)
+    b = torch.rand(nb, Nq, heads, generator=g) * 2 - 1
+    q = 0.7 * torch.randn(nb, Nq, heads, d, generator=g) + b[..., None] * u
+    k = 0.7 * torch.randn(nb, Nq, heads, d, generator=g) + (amp * torch.linspace(0.0, 1.0, Nq))[None, :, None, None] * u
+    v = torch.randn(nb, Nq, heads, d, generator=g)
+    q16, k16, v16 = (t.reshape(nb * Nq, C).half().to(dev) for t in (q, k, v))
+    Q, K, V = (_heads(t, nb, Nq, heads, d) for t in (q16, k16, v16))
+    ref = ((Q @ K.transpose(-1, -2)) * d ** -0.5).softmax(-1) @ V
+
+    def wrong(out):
+        e = (_heads(out, nb, Nq, heads, d) - ref).abs()
+        return int((e > 1e-2 + 1e-2 * ref.abs()).sum())
+    rows = []
+    o, _ = ops.attn_fwd(q16, k16, v16, Nq, Nq, heads, d, nb)
+    rows.append(dict(lib="shipped", wrong_elements=wrong(o), elements=o.numel()))
+    assert rows[0]["wrong_elements"] == 0
+    if os.path.exists(build.TRANS_HAZARD_CONTROL_LIB):
+        ctl = ctypes.CDLL(build.TRANS_HAZARD_CONTROL_LIB)
+        ctl.mc_attn_fwd_f16.argtypes = lib.SIGNATURES["mc_attn_fwd_f16"]
+        ctl.mc_attn_fwd_f16.restype = ctypes.c_int
+        worst = 0
+        for _ in range(5):
+            oc = torch.empty_like(o)
+            rc = ctl.mc_attn_fwd_f16(q16.data_ptr(), k16.data_ptr(), v16.data_ptr(), q16.stride(0), k16.stride(0), v16.stride(0),
+                                     oc.data_ptr(), oc.stride(0), None, Nq, Nq, heads, d, nb, 1, float(d ** -0.5),
+                                     torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            torch.cuda.synchronize()
+            worst = max(worst, wrong(oc))
+        bad = (_heads(oc, nb, Nq, heads, d) - ref).abs() > 1e-2 + 1e-2 * ref.abs()
+        chans = sorted(set(bad.nonzero()[:, 3].tolist()))
+        rows.append(dict(lib="control without the s_nop", wrong_elements_worst_of_5=worst, elements=o.numel(), wrong_head_dims=chans))
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open(os.path.join("gpurun_out", "attn_trans_hazard_r05.json"), "w") as f:
+        json.dump(rows, f, indent=1)
+    print("TRANS_HAZARD", json.dumps(rows))
+
+
 def test_attention_xcd_block_mapping_is_the_same_arithmetic(backend, monkeypatch):
     """attention.hip attn_block: the 1-D launch that keeps all row blocks of one (batch, head) on one XCD only renames
     workgroups, so forward and backward are bit-identical to the plain (row block, head, batch) grid - also when the number
