@@ -449,8 +449,8 @@ def test_self_attention_long_sequence_takes_four_query_tiles_per_wave(backend):
     close(_heads(dqkv[:, 2 * C:], nb, Nq, heads, d), gv, 1e-2, 2e-2, "attn dv, 4 tiles per wave")
 
 
-@pytest.mark.parametrize("d", [40, 80])
-def test_attention_rows_that_outgrow_their_first_tile(backend, d):
+@pytest.mark.parametrize("d,long_", [(40, False), (80, False), (40, True)], ids=["d40", "d80", "d40-4-tiles-per-wave"])
+def test_attention_rows_that_outgrow_their_first_tile(backend, d, long_):
     """The ring forward keeps a per-row softmax OFFSET (not the running maximum) and re-bases it only when a score exceeds it by
     more than 2^8 (attention.hip: kRebase).  On N(0, 1) operands that happens at the first key tile and almost never again, so
     the re-base of a row that already HAS accumulated output was not exercised - and on the MI355X it was wrong: the rescale
@@ -461,6 +461,8 @@ def test_attention_rows_that_outgrow_their_first_tile(backend, d):
     The host simulator has no such hazard: it checks the re-base arithmetic; the GPU run is the regression test."""
     dev = backend
     Nq, heads, nb = (1024, 1, 1) if not big(dev) else (1024 + 128, 4, 3)
+    if long_:                      # Nq >= 2048 at d = 40: the 256-row workgroup, four query tiles per wave (level 0 at 512 x 512)
+        Nq, heads, nb = (2048, 1, 1) if not big(dev) else (2048 + 64, 4, 2)
     C = heads * d
     g = torch.Generator().manual_seed(21)
     u = torch.randn(heads, d, generator=g)

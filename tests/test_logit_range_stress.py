@@ -135,3 +135,26 @@ def test_temporal_attention_with_wide_logits(backend, F_, d):
     close(dqkv[:, :C], _temporal_unref(gq, B, F_, HW, heads, d), 1e-2 * float(gq.abs().max()), 2e-2, "tattn dq, wide logits")
     close(dqkv[:, C:2 * C], _temporal_unref(gk, B, F_, HW, heads, d), 1e-2 * float(gk.abs().max()), 2e-2, "tattn dk, wide logits")
     close(dqkv[:, 2 * C:], _temporal_unref(gv, B, F_, HW, heads, d), 1e-2 * float(gv.abs().max()), 2e-2, "tattn dv, wide logits")
+
+
+@pytest.mark.parametrize("d,N,span", [(40, 1024, 300.0), (80, 1024, 300.0), (160, 256, 300.0), (40, 1024, 1500.0)])
+def test_attention_forward_with_extreme_logit_ranges(backend, d, N, span):
+    """"Attention sinks" / massive activations: rows whose logits span hundreds of log2 units, so that almost all probabilities
+    underflow and the running offset moves dozens of times (ring kernels at N = 1024, the flash kernel at d = 160): forward and
+    log-sum-exp against fp32 torch, finite, bit-stable.  (1500 units: q . k reaches ~1000 in natural units, the offset's fp16
+    rounding is 0.5 - 1 there and must cancel in the normalisation as attention.hip claims.)"""
+    dev = backend
+    heads, nb = (1, 1) if not big(dev) else (4, 2)
+    C = heads * d
+    q, k, v = ramped(nb, N, N, heads, d, span, 61)
+    q16, k16, v16 = (t.reshape(nb * N, C).half().to(dev) for t in (q, k, v))
+    assert torch.isfinite(k16.float()).all()
+    o, lse = ops.attn_fwd(q16, k16, v16, N, N, heads, d, nb)
+    o2, lse2 = ops.attn_fwd(q16, k16, v16, N, N, heads, d, nb)
+    assert torch.equal(o, o2) and torch.equal(lse, lse2)
+    Q, K, V = (_heads(t, nb, N, heads, d) for t in (q16, k16, v16))
+    S = (Q @ K.transpose(-1, -2)) * d ** -0.5
+    close(_heads(o, nb, N, heads, d), S.softmax(-1) @ V, 1e-2, 1e-2, "attn fwd, %g log2 units" % span)
+    # the kernels multiply q by scale * log2(e) in fp16 before the MFMA: a score carries ~2^-11 of its own size (the reference's fp16
+    # baddbmm output is coarser still: one fp16 ulp of the score itself), so the log-sum-exp bound follows the largest |score|
+    close(lse, torch.logsumexp(S, -1), max(2e-3, 2.0 ** -10 * float(S.abs().max())), 2e-3, "attn lse, %g log2 units" % span)
