@@ -139,10 +139,13 @@ def fp16_weights(sd):
 
 
 def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, ctrl=None, res_u=None, res_c=None,
-                      tol_grad=None, witness_sd16=None):
+                      tol_grad=None, witness_sd16=None, witness_factor=None):
     """witness_sd16 (round 5, SURVEY.md 8c "second witness"): the oracle once more in fp16 on the device (= what the reference
     computes through stock PyTorch: fp16 activations AND an fp16 autograd backward) - its loss / gradient / latents are
-    reported next to the engine's, both measured from the fp32 oracle."""
+    reported next to the engine's, both measured from the fp32 oracle.
+    witness_factor (stress cases on ill-conditioned weights): every bound becomes max(the usual tolerance, factor x the fp16
+    reference's own distance from the fp32 oracle) - "within fp16 tolerance" measured on the spot; the gradient against HALF the
+    witness's (fp16 autograd is the worse of the two by an order of magnitude)."""
     tol_grad = TOL_GRAD if tol_grad is None else tol_grad
     ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
     assert smp.timesteps.tolist() == ts.tolist()
@@ -174,10 +177,18 @@ def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, c
         report(key, **{"witness_fp16_oracle_guided_" + k: v for k, v in wit.items()})
         del w_nxt, w_aux
     assert torch.isfinite(aux["grad"]).all() and torch.isfinite(nxt.float()).all()
-    assert e["eps_c"] < TOL_FWD and e["eps_u"] < TOL_FWD, e
-    assert e["loss"] < TOL_LOSS, e
+    t_eps = t_lat = TOL_FWD
+    t_loss = TOL_LOSS
+    if witness_factor is not None:
+        assert witness_sd16 is not None
+        t_eps = max(TOL_FWD, witness_factor * wit["eps_c"])
+        t_lat = max(TOL_FWD, witness_factor * wit["latents"])
+        t_loss = max(TOL_LOSS, witness_factor * wit["loss"])
+        tol_grad = max(tol_grad, 0.5 * wit["grad"]) if wit["grad"] == wit["grad"] else tol_grad
+    assert e["eps_c"] < t_eps and e["eps_u"] < t_eps, e
+    assert e["loss"] < t_loss, e
     assert e["grad"] < tol_grad, e
-    assert e["latents"] < TOL_FWD, e
+    assert e["latents"] < t_lat, e
     return nxt, ref_nxt
 
 
