@@ -442,3 +442,19 @@ def test_outlier_channels_stress(world, variant):
         worst = max(worst, e / max(ew, 1e-12))
     PU.report(key, plain_steps_engine_error_over_fp16_reference_error_max=worst)
     torch.cuda.empty_cache()
+
+
+def test_non_square_frames(world):
+    """The reference takes any --H / --W (t2v_video_sample.py:118-120); every BASELINE config is square.  320 x 512 pixels = a 40 x 64
+    latent (levels 2560 / 640 / 160 / 40 tokens: the level-0 attention on the ring kernel with a ragged last key tile... none of the
+    level sizes is a power of two): forward, extraction, guided and plain step against the oracle, usual tolerances."""
+    dev, cfg, sd, eng, sdo = world
+    F, H, W = 16, 40, 64
+    key = "nonsquare_16f_320x512"
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 30, 18, 0.4)
+    PU.check_forward_b2(eng, sdo, cfg, lat, text, int(smp.timesteps[0]), key)
+    _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, tol_grad=PU.TOL_GRAD_FULLSIZE)
+    PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
+    torch.cuda.empty_cache()
