@@ -458,3 +458,19 @@ def test_non_square_frames(world):
     nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, tol_grad=PU.TOL_GRAD_FULLSIZE)
     PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
     torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("F", [8, 24])
+def test_other_frame_counts(world, F):
+    """--L other than 16 / 32 (the PE table allows up to 32 frames, motion_module.py:60): 8 frames (half a temporal tile) and 24
+    (one and a half), 32 x 32 latents: forward, extraction, guided and plain step against the oracle."""
+    dev, cfg, sd, eng, sdo = world
+    H = W = 32
+    key = "frames_%d_256" % F
+    lat, text, vid, noise = PU.synth_inputs(cfg, F, H, W, dev)
+    smp = sampler(eng, 10, 5, 0.3)
+    PU.check_forward_b2(eng, sdo, cfg, lat, text, int(smp.timesteps[0]), key)
+    _, rep_ref, _ = PU.check_extraction(eng, smp, sdo, cfg, vid, noise, text, key)
+    nxt, _ = PU.check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, 0, key, tol_grad=PU.TOL_GRAD_FULLSIZE)
+    PU.check_plain_step(eng, smp, sdo, cfg, nxt, text, smp.G, key)
+    torch.cuda.empty_cache()
