@@ -296,7 +296,7 @@ def compact_line(res, detail_path, limit=4000):
     if r:
         line["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
                                                   "traffic_vs_algorithmic", "avg_launch_us", "launches",
-                                                  "share_of_probe_video")}
+                                                  "share_of_probe_video", "regime")}
     rt = res.get("roofline_timed")
     if rt:
         line["roofline_timed"] = {k: rt.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us", "overlap",
