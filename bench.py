@@ -318,22 +318,37 @@ def compact_line(res, detail_path, limit=4000):
     line["detail"] = detail_path
     # never let a long string cost the record (the whole benchmark has run by now): shed, in this order, the prose, the
     # error texts, the optional objects, and finally cut the strings of the contract keys - a line is ALWAYS printed
-    sheds = [lambda: line.get("cpu_baseline", {}).pop("sample", None),
-             lambda: [c.__setitem__("error", str(c["error"])[:120]) for c in (line.get("cpu_baseline"),) if c and "error" in c],
-             lambda: line.pop("roofline_timed", None),
-             lambda: line.pop("cpu_baseline", None),
-             lambda: line.pop("roofline", None),
-             lambda: [line.pop(k, None) for k in list(line) if k not in keep and k != "detail"],
-             lambda: line.get("config", {}).__setitem__("workload", str(line.get("config", {}).get("workload", ""))[:160]),
-             lambda: line.__setitem__("metric", str(line.get("metric", ""))[:160]),
-             lambda: line.__setitem__("config", {"workload": str(line.get("config", {}).get("workload", ""))[:80]}),
-             lambda: [line.pop(k, None) for k in list(line) if k not in ("metric", "value", "unit", "n_gpus", "steps", "warmup",
-                                                                            "ms_per_step", "higher_is_better")]]
+    contract = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better")
+
+    def shed(stage):
+        cb, cfg = line.get("cpu_baseline"), line.get("config", {})
+        if stage == 0 and cb:
+            cb.pop("sample", None)
+        elif stage == 1 and cb and "error" in cb:
+            cb["error"] = str(cb["error"])[:120]
+        elif stage == 2:
+            line.pop("roofline_timed", None)
+        elif stage == 3:
+            line.pop("cpu_baseline", None)
+        elif stage == 4:
+            line.pop("roofline", None)
+        elif stage == 5:
+            for k in [k for k in line if k not in keep and k != "detail"]:
+                line.pop(k)
+        elif stage == 6:
+            cfg["workload"] = str(cfg.get("workload", ""))[:160]
+        elif stage == 7:
+            line["metric"] = str(line.get("metric", ""))[:160]
+        elif stage == 8:
+            line["config"] = {"workload": str(cfg.get("workload", ""))[:80]}
+        elif stage == 9:
+            for k in [k for k in line if k not in contract]:
+                line.pop(k)
     out = json.dumps(line)
-    for shed in sheds:
+    for stage in range(10):
         if len(out) <= limit:
             break
-        shed()
+        shed(stage)
         out = json.dumps(line)
     return out
 
