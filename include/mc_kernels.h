@@ -20,6 +20,7 @@
 #ifndef MC_KERNELS_H
 #define MC_KERNELS_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -63,6 +64,20 @@ long mc_workspace_bytes_tattn_loss(int B, int HW, int heads);
 int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
+
+/* Persistent tile loop over the 256x320 tile (gemm6.hip, round 6): the same product as mc_gemm_f16 (DENSE, bit-identical to
+ * its 256x320 kernel) with ONE workgroup per CU walking the output tiles and the LDS operand ring running through tile
+ * boundaries - for the wide-N short-K Linear layers (diffusers FeedForward's first Linear at attention.py:211,288 /
+ * motion_module.py:209,222; to_q|k|v at attention.py:355-357), where a tile's fixed cost is a third of its k-loop.
+ *   workspace: mc_workspace_bytes_gemm_tileloop() bytes, ZERO at kernel start: per-XCD tile counters of the dynamic tile order;
+ *     the kernel zeroes them again before it ends (no memset per launch; launches that may overlap need separate blocks);
+ *     null = static tile order.
+ *   flags: 0x200 fused GEGLU; 0x1 A/B: drain the epilogue's stores before the next tile's first wait; bits 16-23 grid cap / 8.
+ * Returns MC_ERR_UNSUPPORTED (-2) outside its shapes (K < 256, M < 1793, N % 8): call mc_gemm_f16. */
+long mc_workspace_bytes_gemm_tileloop(void);
+int mc_gemm_tileloop_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
+                         int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int rows_per_batch, float alpha,
+                         int flags, void* workspace, size_t ws_bytes, void* stream);
 
 /* PROFILING ONLY: the kernel structure used by the calling thread's last mc_gemm_f16 / mc_gemm_splitk_f16 call:
  * 2 / 20 = gemm2 128x128 / 64x64 tiles, 31..35 = gemm3 geometry 1..5, 4 = gemm4, 51 / 54 = gemm5 with 256- / 128-row tiles;

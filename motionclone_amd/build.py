@@ -12,7 +12,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 REPO = os.path.dirname(HERE)
-SOURCES = ["gemm_api.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "gemm5.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
+SOURCES = ["gemm_api.hip", "gemm2.hip", "gemm3.hip", "gemm4.hip", "gemm5.hip", "gemm6.hip", "norm.hip", "elementwise.hip", "temporal.hip", "attention.hip"]
 HIP_LIB = os.path.join(CSRC, "libmotionclone_hip.so")
 EMU_DIR = os.path.join(REPO, "tests", "hipemu")
 EMU_LIB = os.path.join(EMU_DIR, "_build", "libmc_emu.so")
@@ -24,6 +24,10 @@ EMU_LIB = os.path.join(EMU_DIR, "_build", "libmc_emu.so")
 # costs two v_fma_f32 issue slots beside MFMAs anyway).
 HIP_FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffast-math", "-fno-finite-math-only",
              "-fno-slp-vectorize"]
+# gemm6.hip: hipcc's atomic optimizer turns the tile counter's one-lane atomicAdd into a wave reduction whose result is read (and
+# waited for with s_waitcnt vmcnt(0): a drain of the operand ring) right behind the atomic; left alone, the compiler waits for
+# the value where the source reads it - behind the epilogue - with an exact count
+FILE_FLAGS = {"gemm6.hip": ["-mllvm", "-amdgpu-atomic-optimizer-strategy=None"]}
 # TEST ONLY: csrc/temporal.hip with the SLP vectoriser ON = the build whose backward went wrong in round 2; the negative
 # control of tests/test_determinism.py (never loaded by the package)
 SLP_CONTROL_LIB = os.path.join(REPO, "tools", "_build", "libtattn_slp.so")
@@ -61,7 +65,7 @@ def build_hip(force=False, verbose=False, tools=False):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     flags = HIP_FLAGS + (["-DMC_TOOLS"] if tools else [])
     out_lib = TOOLS_LIB if tools else HIP_LIB
-    stamp = _stamp(_deps(), " ".join(flags))
+    stamp = _stamp(_deps(), " ".join(flags) + repr(sorted(FILE_FLAGS.items())))
     stamp_file = out_lib + ".stamp"
     if not force and os.path.exists(out_lib) and os.path.exists(stamp_file):
         if open(stamp_file).read() == stamp:
@@ -71,7 +75,7 @@ def build_hip(force=False, verbose=False, tools=False):
 
     def one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        out = _run([hipcc] + flags + ["-c", os.path.join(CSRC, src), "-o", obj])
+        out = _run([hipcc] + flags + FILE_FLAGS.get(src, []) + ["-c", os.path.join(CSRC, src), "-o", obj])
         if verbose and out.strip():
             print(out)
         return obj

@@ -1,0 +1,555 @@
+// Persistent tile loop over gemm5's 256x320 tile (round 6): ONE 8-wave workgroup per CU walks a list of output tiles and
+// the operand ring never stops at a tile boundary.
+//
+// Why (profiles/r05_vendor_anchor.md): on the wide-N short-K Linear layers (FeedForward's first Linear,
+// q|k|v of the 1280-channel level: attention.py:211,288,355-357, motion_module.py:209,222) gemm5's k-loop already runs at
+// the vendor library's rate, but every 256x320 tile pays ~8.5 us that is not k-loop - ~5.5 us of it the prologue: all
+// 256 workgroups of a dispatch wave fill three ring stages at the same moment, and nothing is multiplied until the first
+// one lands.  Here a workgroup starts that burst once per LAUNCH:
+//
+//   * flat stage stream: stage g of the workgroup's work list belongs to tile g / nk; the LDS-DMA loads of stage g + 3
+//     are issued while stage g is multiplied, whichever tile they belong to, so the first three stages of tile t + 1 land
+//     under the last three k-steps and the epilogue of tile t;
+//   * the epilogue keeps the ring: its fp16 images are 32 rows x 80 columns per wave (5.5 KiB; gemm5: 32 x 160) and live in
+//     the ONE ring slot that is free at a tile boundary (waves 0-5) plus 11 KiB behind the ring (waves 6-7) - the three
+//     prefetched stages of the next tile stay where they are.  A 64 x 160 wave tile leaves in four passes (two for the
+//     fused GEGLU) instead of two;
+//   * epilogue loads / stores go through buffer descriptors with the hardware range check, so a wave issues the SAME number
+//     of vector-memory instructions for every tile (no predicated-off instruction): the counted s_waitcnt vmcnt of the two
+//     stages that follow an epilogue allow exactly the epilogue's stores on top of the ring's loads (vmcnt retires in issue
+//     order on gfx9: the ring of gemm5 already relies on it for LDS-DMA; VAR bit 0 builds the variant that does not extend
+//     the assumption to stores - every wait as in the steady state, i.e. the stores are drained at the first k-step);
+//   * tile order: XCD x owns the M-tiles tm = 8 i + x and walks them in super-tiles (gemm5's order: the activation rows of sm
+//     tiles and the weight rows of sn tiles are what an XCD's 32 workgroups share in their 4 MiB L2).  STATIC: workgroup
+//     (x, s) takes locals s, s + S, ... of its XCD's list.  DYNAMIC (ctr != null): the first local is s, every further one
+//     comes from a per-XCD counter word (device-scope atomic, requested by one lane at the START of an epilogue and read at
+//     its end - the compiler's own exact vmcnt wait, no drain of the ring - for the tile AFTER the one already being loaded,
+//     handed to the other waves through LDS) - a workgroup that starts late because another launch sequence holds its CU
+//     takes fewer tiles instead of finishing its whole list late.  The counter block (9 words) is zero when the kernel starts and the LAST workgroup to
+//     leave zeroes it again (arrival count in word 8), so a caller hands the same zero-initialised words to every launch of a
+//     stream (graph replays included) without a memset node.
+//
+// Output is bit-identical to gemm5's: every output element is one fp32 accumulation chain along k in the same order.
+// DENSE only (the 3x3 convs of these levels fill the chip with one round of tiles and are not short-K).
+#include "gemm5_tile.hpp"
+
+namespace mc {
+
+namespace g6 {
+using T = g5::Tile<256>;
+constexpr int IMG = 32 * g5::RSG;                // one wave's epilogue image: 32 rows x (80 columns + 16 B) = 5632 B
+constexpr int IMG_IN_SLOT = 6;                   // waves 0..5 inside the free ring slot, 6..7 behind the ring
+constexpr int BSTRIP = 640;                      // one wave's bias strip: 160 fp32
+constexpr int TAIL = 2 * IMG + 4 * BSTRIP;       // behind the ring: images of waves 6-7, bias strips of waves 4-7
+constexpr size_t SMEM = T::SMEM + TAIL + 16;     // ... and the tile hand-over word
+constexpr int NK_MIN = 8;                        // stages per tile the schedule assumes at least (K >= 256)
+static_assert(IMG_IN_SLOT * IMG + 4 * BSTRIP <= T::STAGE && SMEM <= 160 * 1024, "epilogue images: one ring slot + the tail");
+
+// local index `l` of XCD `xcd`'s tile list -> (tm, tn); false past the end.  Rows of the XCD: tm = 8 i + xcd, walked in groups
+// of sm rows, inside a group in column blocks of sn tiles, rows fastest (gemm5's super-tile order without holes).
+__device__ __forceinline__ bool tile_of(int l, int xcd, int tilesM, int tilesN, int sm, int sn, int& tm, int& tn) {
+    const int rows = (tilesM - xcd + 7) >> 3;
+    if (l >= rows * tilesN) return false;
+    const int per_group = sm * tilesN;
+    const int g = l / per_group, idx = l - g * per_group;
+    const int rg = min(sm, rows - g * sm);
+    const int blk = idx / (rg * sn), w = idx - blk * (rg * sn);
+    tn = blk * sn + w / rg;
+    tm = (g * sm + w % rg) * 8 + xcd;
+    return true;
+}
+}  // namespace g6
+
+// Everything the kernel is told, in ONE by-value block: the parts only the epilogue / the tile switch read are fetched there
+// through a laundered pointer (scalar loads at the point of use) instead of living in SGPRs across the k-loop, which has
+// none to spare (the first build spilled 78 of them into VGPR lanes and 35 VGPRs to scratch).
+struct G6Args {
+    GemmParams p;
+    uint32_t bytesA, bytesW, bytesC, bytesR, bytesB;
+    int tilesM, tilesN, sm, sn;
+    uint32_t* ctr;
+};
+#ifdef MC_EMU
+#define MC_SCHED_FENCE() ((void)0)
+#define G6_ARGS (&args)      // simulator: the parameter is an ordinary object
+typedef const G6Args* g6args_t;
+__device__ inline g6args_t late(const G6Args* a) { return a; }
+#else
+// (the kernarg segment is constant memory: through an address_space(4) pointer held in SGPRs every field is an s_load and stays
+// wave-uniform - through a laundered GENERIC pointer the fields came back as flat loads in VGPRs and every buffer instruction of
+// the epilogue was wrapped in a waterfall loop)
+#define MC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define G6_ARGS nullptr      // device: never take the parameter's address (see `late`)
+typedef const G6Args __attribute__((address_space(4)))* g6args_t;
+__device__ __forceinline__ g6args_t late(const G6Args*) {
+    // the block is the kernel's only parameter: offset 0 of the kernarg segment.  (Taking the parameter's address instead
+    // makes hipcc copy it to scratch and read EVERYTHING - the operand descriptors of the k-loop included - back through VGPRs.)
+    uint64_t v = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(v));
+    return (g6args_t)v;
+}
+#endif
+
+// The lane index, recomputed where it is needed (two VALU instructions) instead of kept: nothing inside the k-loop reads it,
+// so a lane index (or anything derived from it) that lives across the loop is spilled to scratch, and every reload is a
+// scratch_load + s_waitcnt vmcnt(0) - a drain of the operand ring and of the epilogue's stores.  `opaque` keeps hipcc from
+// hoisting the recomputation (and every address that depends on it) back out of the tile loop.
+#ifdef MC_EMU
+__device__ inline int lane_now() { return (int)(threadIdx.x & 63); }
+#else
+__device__ __forceinline__ int lane_now() {
+    return opaque((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+}
+#endif
+
+// one 32-bit word of LDS, explicitly in the LDS address space: through a `volatile uint32_t*` the hand-over word became a FLAT
+// access with s_waitcnt vmcnt(0) - a drain of the operand ring - in front of it
+#ifdef MC_EMU
+__device__ inline uint32_t lds_ld32(const char* p) { return *reinterpret_cast<const volatile uint32_t*>(p); }
+__device__ inline void lds_st32(char* p, uint32_t v) { *reinterpret_cast<volatile uint32_t*>(p) = v; }
+#else
+__device__ __forceinline__ uint32_t lds_ld32(const char* p) {
+    uint32_t v;
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const char*)p;
+    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(a) : "memory");
+    return v;
+}
+__device__ __forceinline__ void lds_st32(char* p, uint32_t v) {
+    const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)p;
+    asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+#endif
+
+// Epilogue of one wave tile (64 x 160 at (mw0, nw0)) through a 32 x 80-column image `stg`.  EPI 0: two column halves per
+// 32-row block (four passes); EPI 1 (fused GEGLU, 80 outputs per row): two passes.
+//
+// vmcnt retires in issue order, so waiting for a LOAD also waits for every STORE issued before it.  The epilogue is
+// therefore written so that no wait ever reaches the stores of the pass in front of it:
+//   * STRAIGHT-LINE code, every load / store a buffer instruction with the hardware range check instead of a predicate:
+//     the compiler's own waits are exact counts (a load inside an exec-masked branch is waited for with vmcnt(0)), and a wave
+//     issues the same number of vector-memory instructions for every tile - the callers' vmcnt arithmetic depends on it;
+//   * the bias (one row: rows_per_batch >= M) does not come from vector memory at all here: the caller fetched the wave's 160
+//     values with ONE load a k-stage ago (`bias4`: lane l holds columns 4 l .. 4 l + 3), they go through a wave-private LDS
+//     strip `bstrip` and every accumulator chunk reads its four with a broadcast ds_read_b128;
+//   * the residual rows of pass p + 1 are requested BEFORE the stores of pass p are issued (two register sets).
+// Bias added in fp32 before the fp16 rounding, residual added to the rounded value: the reference's order
+// (attention.py:293-299) and gemm5's, bit for bit.
+template <int EPI, int RES, int TM>
+__device__ __forceinline__ void g6_epilogue(const G6Args* ap, f32x16 (&acc)[g5::TN][TM], char* stg, char* bstrip, f32x4 bias4,
+                                            int mw0, int nw0) {
+    using namespace g5;
+    constexpr int H = EPI == 1 ? 1 : 2;               // passes per 32-row block
+    constexpr int NP = TM * H;                        // passes
+    constexpr int CPP = 20 / H;                       // accumulator chunks (i, q) per pass
+    constexpr int CB = 5;                             // chunks per scheduling group
+    constexpr int PITCH = RSG, SEGS = 10, RPI_OUT = 6, NIT = 6;
+    const g6args_t a = late(ap);
+    const int M = a->p.M, N = a->p.N, ldc = a->p.ldc, ldr = a->p.ldr;
+    const float alpha = a->p.alpha;
+    constexpr bool has_r = EPI == 0 && RES != 0;
+    const bool has_b = a->p.bias != nullptr;
+    const GBuf bufC = make_gbuf(a->p.C, a->bytesC);
+    const GBuf bufR = make_gbuf(has_r ? (const void*)a->p.R : (const void*)a->p.C, has_r ? a->bytesR : 0u);
+    const int lane = lane_now();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == 6 -> out of range
+    const int nout = EPI == 1 ? N / 2 : N;
+    if (has_b) {
+        if (lane < 40) *reinterpret_cast<f32x4*>(bstrip + lane * 16) = bias4;
+    }
+    half8_t rres[has_r ? 2 : 1][NIT];
+    auto load_r = [&](int pass, half8_t* dst) {
+        const int mrow = mw0 + 32 * (pass / H);
+        const int ncol = nw0 + 80 * (pass % H) + seg * 8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel, m = mrow + r;
+            const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
+            dst[it] = gbuf_ld8(bufR, ok ? ((uint32_t)m * (uint32_t)ldr + (uint32_t)ncol) * 2u : kOOB);
+        }
+    };
+    if (has_r) load_r(0, rres[0]);
+    wave_lds_sync();                                  // the bias strip is readable
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int j = pass / H, h = pass % H;
+        const int mrow = mw0 + 32 * j;
+        const int ncol = EPI == 1 ? nw0 / 2 + seg * 8 : nw0 + 80 * h + seg * 8;   // first output column of the lane's segment
+#pragma unroll
+        for (int c0 = 0; c0 < CPP; c0 += CB) {
+            f32x4 bv[CB];
+            if (has_b) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const int iq = h * CPP + c0 + c;
+                    bv[c] = *reinterpret_cast<const f32x4*>(bstrip + (32 * (iq >> 2) + 8 * (iq & 3) + 4 * lhi) * 4);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int iq = h * CPP + c0 + c, i = iq >> 2, q = iq & 3;
+                const int cl = 32 * i + 8 * q + 4 * lhi;   // column within the wave's 160
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * alpha;
+                if (has_b) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[c][e];
+                }
+                if (EPI == 1) {   // fused GEGLU: columns are (h, gate) pairs
+                    half2_t o;
+                    o[0] = to_half(v[0] * gelu_f(v[1]));
+                    o[1] = to_half(v[2] * gelu_f(v[3]));
+                    *reinterpret_cast<half2_t*>(stg + l31 * PITCH + cl) = o;
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + (cl - 80 * h) * 2) = o;
+                }
+            }
+            MC_SCHED_FENCE();   // keeps hipcc from hoisting every chunk's arithmetic to the top (spills: each reload is a vmcnt(0))
+        }
+        wave_lds_sync();
+        if (has_r && pass + 1 < NP) load_r(pass + 1, rres[has_r ? (pass + 1) & 1 : 0]);   // in front of this pass's stores
+        MC_SCHED_FENCE();
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel, m = mrow + r;
+            const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
+            half8_t o = *reinterpret_cast<const half8_t*>(stg + min(r, 31) * PITCH + seg * 16);
+            if (has_r) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] = to_half((float)o[e] + (float)rres[has_r ? pass & 1 : 0][it][e]);
+            }
+            gbuf_st8(bufC, ok ? ((uint32_t)m * (uint32_t)ldc + (uint32_t)ncol) * 2u : kOOB, o);
+        }
+        wave_lds_sync();   // the image is rewritten by the next pass
+        MC_SCHED_FENCE();
+    }
+}
+
+template <int EPI, int RES, int VAR>
+__global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
+    using g5::TN; using g5::BKT; using g5::RPI; using g5::lds_off32;
+    using T = g6::T;
+    constexpr int NW = g5::NW, NS = g5::NS, BM = 256, BN = g5::BN;
+    constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB, WB = T::WB, WX = T::WX;
+    constexpr int WMW = T::WMW;
+    constexpr int ST = TM * (EPI == 1 ? 1 : 2) * 6;   // buffer stores one epilogue issues per wave, always
+    static_assert(NS == 4 && LA + ST + LA < 64, "vmcnt is a 6-bit counter");
+    MC_DYN_SMEM(smem);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+#ifdef MC_EMU
+    const int wave = tid >> 6;
+#else
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#endif
+    const bool grpA = wave < WX;
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int nk = args.p.K / BKT;
+    const bool dynamic = args.ctr != nullptr;
+    char* handover = smem + T::SMEM + g6::TAIL;
+
+    const GBuf bufA = make_gbuf(args.p.A, args.bytesA);
+    const GBuf bufW = make_gbuf(args.p.W, args.bytesW);
+
+    // the last workgroup to leave zeroes the counter block for the next launch that is handed the same words
+    auto leave = [&]() {
+        if (dynamic && tid == 0) {
+            uint32_t* ctr = late(G6_ARGS)->ctr;
+            const uint32_t before = atomicAdd(ctr + 8, 1u);
+            if (before == gridDim.x - 1) {
+#pragma unroll
+                for (int i = 0; i < 9; ++i) ctr[i] = 0u;
+            }
+        }
+    };
+
+    // ---- the tile whose operands are being LOADED (at most one tile ahead of the one being multiplied) -------------------
+    int l_m0 = 0, l_n0 = 0;
+    bool l_valid = false;
+    uint32_t a_off[RA], w_off[WB + 1];   // byte offset of the lane's 16 bytes at k = 0, or kOOB: hardware zero fill
+    auto setup_offsets = [&]() {     // the lane's operand offsets of the load tile (recomputed after every epilogue, see lane_now)
+        const g6args_t q = late(G6_ARGS);
+        const int ln = lane_now(), rsub = ln >> 2, lslot = (ln & 3) ^ (ln >> 4);
+        const int M = q->p.M, N = q->p.N, lda = q->p.lda, K = q->p.K;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = l_m0 + (wave + NW * i) * RPI + rsub;
+            a_off[i] = (l_valid && m < M) ? ((uint32_t)m * (uint32_t)lda + (uint32_t)lslot * 8u) * 2u : kOOB;
+        }
+#pragma unroll
+        for (int i = 0; i <= WB; ++i) {
+            const int n = l_n0 + (i < WB ? wave + NW * i : WB * NW + (wave % WX)) * RPI + rsub;
+            w_off[i] = (l_valid && n < N) ? (uint32_t)n * (uint32_t)K * 2u + (uint32_t)lslot * 16u : kOOB;
+        }
+    };
+    auto setup_tile = [&](int local) {   // scalar part
+        const g6args_t q = late(G6_ARGS);
+        int tm = 0, tn = 0;
+        l_valid = g6::tile_of(local, xcd, q->tilesM, q->tilesN, q->sm, q->sn, tm, tn);
+        l_m0 = tm * BM;
+        l_n0 = tn * BN;
+    };
+    // one LDS-DMA instruction of k-stage kt of the load tile into ring slot buf: pieces 0 .. RA-1 activation row groups,
+    // then 2 (3) weight row groups (kOOB + a small offset stays out of range)
+    auto issue_piece = [&](int kt, int buf, int piece) {
+        char* base = smem + buf * STAGE;
+        const uint32_t kb = (uint32_t)kt * (BKT * 2u);
+        if (piece < RA) {
+            glds16(bufA, a_off[piece] + kb, base + (wave + NW * piece) * 1024);
+        } else {
+            const int i = piece - RA;
+            glds16(bufW, w_off[i] + kb, base + A_BYTES + (i < WB ? wave + NW * i : WB * NW + (wave % WX)) * 1024);
+        }
+    };
+    // ---- work list ----------------------------------------------------------------------------------------------------------
+    int t_load = slot;
+    int t_next = slot + nslots;          // static order; dynamic: replaced by the counter's answers
+    setup_tile(t_load);
+    if (!l_valid) {
+        leave();
+        return;
+    }
+    // dynamic order: the second tile's index is requested now and handed over after the prologue's wait (which covers it:
+    // vmcnt retires in issue order and the request is older than every operand load)
+    uint32_t ticket = 0;
+    if (dynamic && wave == 0 && lane == 0) ticket = atomicAdd(args.ctr + xcd, 1u);
+    int c_m0 = l_m0, c_n0 = l_n0;        // the tile being multiplied
+
+    f32x16 acc[TN][TM];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+
+    const int wr = wave % WMW, wc = wave / WMW;
+    const int wm0 = wr * (32 * TM), wn0 = wc * 160;
+    int lkt = 0;                         // next k-stage of the load tile
+
+    half8_t fa[2][TM], fw[2][TN];
+    int l31 = 0, lhi = 0;            // set right before their first use and again after every epilogue: nothing lane-derived
+                                     // lives across an epilogue (see lane_now)
+    auto load_frags = [&](int buf, int ks, half8_t* a, half8_t* w) {
+        const char* bA = smem + buf * STAGE;
+        const char* bW = bA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            a[j] = *reinterpret_cast<const half8_t*>(bA + lds_off32(wm0 + 32 * j + l31, 2 * ks + lhi));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            w[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * ks + lhi));
+    };
+    // half a stage, exactly gemm5's scheduling region: MFMAs of the current k-slice, fragment reads of the next one, NL LDS-DMA
+    // instructions (pieces P0 ..) of load-tile stage `lk` into slot `lbuf`
+    auto half_step = [&](auto nl_tag, auto p0_tag, int rbuf, int rks, half8_t* ra, half8_t* rw, const half8_t* ca, const half8_t* cw,
+                         int lk, int lbuf) {
+        constexpr int NL = decltype(nl_tag)::value;
+        constexpr int P0 = decltype(p0_tag)::value;
+        static_assert(NL <= TN, "one LDS-DMA behind each weight fragment at most");
+        const char* bA = smem + rbuf * STAGE;
+        const char* bW = bA + A_BYTES;
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            ra[j] = *reinterpret_cast<const half8_t*>(bA + lds_off32(wm0 + 32 * j + l31, 2 * rks + lhi));
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(cw[i], ca[j], acc[i][j]);
+            rw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * rks + lhi));
+            if (i < NL) issue_piece(lk, lbuf, P0 + i);
+        }
+#ifndef MC_EMU
+        __builtin_amdgcn_sched_group_barrier(0x100, TM, 0);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            __builtin_amdgcn_sched_group_barrier(0x008, TM, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (i < NL) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);
+        }
+#endif
+    };
+
+    int buf = 0;
+    auto nxt = [](int b) { return b + 1 == NS ? 0 : b + 1; };
+    auto slot_of_new = [](int b) { return b == 0 ? NS - 1 : b - 1; };
+
+    // the load side moves on to the next tile of the list (all waves, uniformly, at the top of a stage)
+    auto advance = [&]() {
+        if (dynamic) {
+            const uint32_t v = lds_ld32(handover);
+#ifdef MC_EMU
+            t_next = (int)v;
+#else
+            t_next = __builtin_amdgcn_readfirstlane((int)v);
+#endif
+        }
+        t_load = t_next;
+        setup_tile(t_load);
+        setup_offsets();
+        lkt = 0;
+        t_next = t_load + nslots;        // (static order)
+    };
+
+    auto run = [&](auto ga_tag) {
+        constexpr bool GA = decltype(ga_tag)::value;
+        constexpr int L = GA ? LA : LB;
+        constexpr int P1 = L < TN ? L : TN, P2 = L - P1;
+        using N1 = std::integral_constant<int, P1>;
+        using N2 = std::integral_constant<int, P2>;
+        using N0 = std::integral_constant<int, 0>;
+        // one k-stage of the compute tile; the loads it issues are stage lkt of the load tile.  EXTRA: vector-memory
+        // instructions younger than the ring stage this wait is about, besides the ring's own (the epilogue's stores)
+        auto stage = [&](auto extra_tag) {
+            constexpr int EXTRA = decltype(extra_tag)::value;
+            const int nbuf = nxt(buf), lbuf = slot_of_new(buf);
+            half_step(N1(), N0(), buf, 1, fa[1], fw[1], fa[0], fw[0], lkt, lbuf);
+            wait_vmcnt_le<L + P1 + EXTRA>();
+            raw_barrier();
+            half_step(N2(), N1(), nbuf, 0, fa[0], fw[0], fa[1], fw[1], lkt, lbuf);
+            buf = nbuf;
+            ++lkt;
+        };
+        using X0 = std::integral_constant<int, 0>;
+        using XS = std::integral_constant<int, (VAR & 1) ? 0 : ST>;
+        // Prologue, once per launch, INSIDE this wave group's copy of the code: whatever is computed per lane in front of
+        // the group branch and used behind it would be spilled across the other group's copy, and a value that is reloaded
+        // from scratch in front of a loop costs an s_waitcnt vmcnt(0) at the loop's header in EVERY iteration (hipcc merges
+        // the header's pending-load state over both incoming edges).
+        setup_offsets();
+        zero_acc();
+#pragma unroll
+        for (int s0 = 0; s0 < NS - 1; ++s0) {
+#pragma unroll
+            for (int q = 0; q < L; ++q) issue_piece(lkt, s0, q);
+            ++lkt;
+        }
+        // stage 0 of the first tile landed: own loads (two younger stages stay in flight), then everybody's
+        wait_vmcnt_le<2 * L>();
+        if (dynamic && wave == 0 && lane_now() == 0) lds_st32(handover, (uint32_t)nslots + ticket);
+        raw_barrier();
+        {
+            const int ln = lane_now();
+            l31 = ln & 31;
+            lhi = ln >> 5;
+        }
+        load_frags(0, 0, fa[0], fw[0]);
+        int k = 0;
+        for (;;) {
+            for (; k < nk - 1; ++k) {
+                if (lkt == nk) advance();
+                stage(X0());
+            }
+            // the tile's last stage, with the wave's 160 bias values requested in front of it (one more load in the queue:
+            // the stage's wait only becomes stricter, and the epilogue's wait for it is an exact count of the ring pieces)
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            {
+                const g6args_t q = late(G6_ARGS);
+                if (q->p.bias) {
+                    const GBuf bufB = make_gbuf(q->p.bias, q->bytesB);
+                    const int ln = lane_now(), n = c_n0 + wn0 + 4 * ln;
+                    bias4 = __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < 40 && n < q->p.N) ? (uint32_t)n * 4u : kOOB));
+                }
+            }
+            stage(X0());
+            // tile finished.  Its last stage's slot (`buf` was advanced past it) is free: every wave read it before the last
+            // barrier; the three younger slots hold / receive the next tile's first stages
+            const int freed = slot_of_new(buf);
+            char* img = wave < g6::IMG_IN_SLOT ? smem + freed * STAGE + wave * g6::IMG
+                                               : smem + T::SMEM + (wave - g6::IMG_IN_SLOT) * g6::IMG;
+            char* bstrip = wave < 4 ? smem + freed * STAGE + g6::IMG_IN_SLOT * g6::IMG + wave * g6::BSTRIP
+                                    : smem + T::SMEM + 2 * g6::IMG + (wave - 4) * g6::BSTRIP;
+            // dynamic order: the index of the tile AFTER the one already being loaded is requested here and read behind the
+            // epilogue (every wave read the previous hand-over word three barriers ago)
+            const bool ask = dynamic && wave == 0 && l_valid && lane_now() == 0;
+            if (ask) ticket = atomicAdd(late(G6_ARGS)->ctr + xcd, 1u);
+            g6_epilogue<EPI, RES, TM>(G6_ARGS, acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
+            if (!l_valid) break;            // the load side ran off the list: nothing real is in flight
+            if (ask) lds_st32(handover, (uint32_t)nslots + ticket);
+            c_m0 = l_m0;
+            c_n0 = l_n0;
+            zero_acc();
+            {
+                const int ln = lane_now();
+                l31 = ln & 31;
+                lhi = ln >> 5;
+            }
+            setup_offsets();
+            raw_barrier();                  // the images are dead: stage + 4's loads may overwrite the freed slot
+            load_frags(buf, 0, fa[0], fw[0]);
+            // the first two stages of the tile: the epilogue's stores sit between the ring loads in the vmcnt queue
+            stage(XS());
+            stage(XS());
+            k = 2;
+        }
+    };
+    if (grpA) run(std::true_type()); else run(std::false_type());
+    wait_vmcnt_le<0>();   // the zero-fill loads issued past the end of the list still write this workgroup's LDS
+    leave();
+}
+
+template <int EPI, int RES, int VAR>
+static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t* ctr, int max_wg, hipStream_t stream) {
+    constexpr int BM = 256, BN = g5::BN;
+    const int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
+    allow_big_smem(gemm6_kernel<EPI, RES, VAR>, g6::SMEM);
+    // super-tile of the XCD-local order: as launch5 (sm x sn ~ the 32 workgroups of an XCD, least operand rows per tile)
+    const int rows_per_xcd = (tM + 7) / 8;
+    int sm = 1, sn = 1;
+    const bool w_resident = (size_t)p.N * p.K * 2 <= (size_t)3 << 20;
+    if (!w_resident) {
+        long best = -1;
+        for (int c = 1; c <= tN && c <= 16; ++c) {
+            if (tN % c) continue;
+            int r = std::max(1, std::min(rows_per_xcd, (32 + c / 2) / c));
+            long cost = ((long)r * BM + (long)c * BN) * 1000 / ((long)r * c);
+            if (best < 0 || cost < best) best = cost, sm = r, sn = c;
+        }
+    }
+    // workgroups per XCD: one per CU, no more than the longest per-XCD list
+    int nslots = std::min(32, rows_per_xcd * tN);
+    if (max_wg > 0) nslots = std::max(1, std::min(nslots, max_wg / 8));
+    const size_t outc = p.epi ? (size_t)p.N / 2 : (size_t)p.N;
+    const size_t bytesC = ((size_t)(p.M - 1) * p.ldc + outc) * 2, bytesR = p.R ? ((size_t)(p.M - 1) * p.ldr + outc) * 2 : 0;
+    if (bytesC > 0x7FFFFFF0u || bytesR > 0x7FFFFFF0u) return MC_ERR_UNSUPPORTED;
+    G6Args a;
+    a.p = p;
+    a.bytesA = bA; a.bytesW = bW; a.bytesC = (uint32_t)bytesC; a.bytesR = (uint32_t)bytesR;
+    a.bytesB = p.bias ? (uint32_t)p.N * 4u : 0u;
+    a.tilesM = tM; a.tilesN = tN; a.sm = sm; a.sn = sn;
+    a.ctr = ctr;
+    MC_LAUNCH((gemm6_kernel<EPI, RES, VAR>), dim3((unsigned)(8 * nslots)), dim3(512), g6::SMEM, stream, a);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// Persistent tile loop for DENSE problems (one activation source, one bias row).  var bit 0: drain the epilogue's stores at
+// the first k-step (no in-order assumption between stores and loads).  ctr: 9 zeroed 32-bit words (dynamic tile order) or null
+// (static).  max_wg: cap on the grid (0 = one workgroup per CU).  MC_ERR_UNSUPPORTED for what stays on gemm5 / gemm3.
+int gemm6_dispatch(const GemmParams& p, int var, uint32_t* ctr, int max_wg, hipStream_t stream) {
+    const size_t bytesA = ((size_t)p.M * (size_t)p.lda) * 2;
+    const size_t bytesW = (size_t)p.N * p.K * 2;
+    const size_t lim = 0x7FFFFFF0u;
+    if (bytesA > lim || bytesW > lim) return MC_ERR_UNSUPPORTED;
+    if (p.A2 || p.c1 != p.K) return MC_ERR_UNSUPPORTED;
+    if (p.bias && p.rows_per_batch < p.M) return MC_ERR_UNSUPPORTED;
+    if (p.ws || p.splits > 1) return MC_ERR_UNSUPPORTED;
+    if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
+    if (p.K / g5::BKT < g6::NK_MIN) return MC_ERR_UNSUPPORTED;
+    if (p.epi == 1 && ((p.N & 15) || p.R)) return MC_ERR_UNSUPPORTED;
+    if ((p.M + 255) / 256 < 8) return MC_ERR_UNSUPPORTED;     // every XCD owns at least one row of tiles
+    if (p.epi == 1) return (var & 1) ? launch6<1, 0, 1>(p, bytesA, bytesW, ctr, max_wg, stream)
+                                     : launch6<1, 0, 0>(p, bytesA, bytesW, ctr, max_wg, stream);
+    if (p.R) return (var & 1) ? launch6<0, 1, 1>(p, bytesA, bytesW, ctr, max_wg, stream)
+                              : launch6<0, 1, 0>(p, bytesA, bytesW, ctr, max_wg, stream);
+    return (var & 1) ? launch6<0, 0, 1>(p, bytesA, bytesW, ctr, max_wg, stream)
+                     : launch6<0, 0, 0>(p, bytesA, bytesW, ctr, max_wg, stream);
+}
+
+}  // namespace mc

@@ -17,6 +17,7 @@ class _Pinned(threading.local):
     stream = None   # HIP stream handle pinned for the duration of one engine call (see `scoped`); per host thread, like
                     # torch's current stream, so engines driven from several threads keep their own streams
     share = None    # tile-policy override of the engine whose call is running (`gemm_lanes` attribute, see `scoped`)
+    owner = None    # the outermost object whose `scoped` call is running: owns the tile-loop counter blocks of its launches
 
 
 _PIN = _Pinned()
@@ -28,7 +29,9 @@ def scoped(fn):
     Evaluated when the method is entered, so a call made under hipGraph capture pins the capturing stream."""
     def wrapper(self, *a, **k):
         pin = _PIN
-        prev, prev_share = pin.stream, pin.share
+        prev, prev_share, prev_owner = pin.stream, pin.share, pin.owner
+        if prev_owner is None:
+            pin.owner = self
         dev = getattr(self, "dev", None)
         if prev is None and dev is not None and dev.type == "cuda":
             pin.stream = torch.cuda.current_stream(dev).cuda_stream
@@ -42,7 +45,7 @@ def scoped(fn):
         try:
             return fn(self, *a, **k)
         finally:
-            pin.stream, pin.share = prev, prev_share
+            pin.stream, pin.share, pin.owner = prev, prev_share, prev_owner
     wrapper.__name__, wrapper.__doc__ = fn.__name__, fn.__doc__
     return wrapper
 
@@ -111,9 +114,81 @@ def gemm_share():
     return _GEMM_SHARE if _PIN.share is None else _PIN.share
 
 
+# ---- persistent tile loop (mc_gemm_tileloop_f16) ------------------------------------------------------------------------
+# Counter blocks of the dynamic tile order: 64 zero bytes per (owner, stream).  The kernel zeroes its block before it ends, and
+# the launches of one owner on one stream (or inside the graphs captured from it) run one after the other, so ONE block per
+# key is enough; keys never share a block, so launch sequences that overlap (lanes) never meet in a counter.  Blocks are cut
+# from a slab that is allocated and zeroed OUTSIDE any graph capture (handing out a block is pointer arithmetic).
+_TILE_SLAB_BLOCKS = 4096
+_tile_slabs = {}     # device -> zeroed int32 tensor
+_tile_blocks = {}    # (id(owner), device, stream) -> byte address
+_tile_lock = threading.Lock()
+TILELOOP = None      # None: the measured policy of `_tileloop_wanted`; False: never; True: wherever the kernel accepts the shape
+
+
+def prepare_tile_counters(device):
+    """allocate the counter slab of `device` (call outside a graph capture; engines do at construction)"""
+    key = str(device)
+    with _tile_lock:
+        if key not in _tile_slabs:
+            _tile_slabs[key] = torch.zeros(_TILE_SLAB_BLOCKS * 16, dtype=torch.int32, device=device)
+    return _tile_slabs[key]
+
+
+def _tile_counter_block(t, stream):
+    """address of the calling owner's zeroed counter block for launches on `stream`, or None (= static tile order) when
+    the slab cannot be created right now (first use inside a graph capture) or is used up"""
+    key = (id(_PIN.owner) if _PIN.owner is not None else 0, str(t.device), stream)
+    addr = _tile_blocks.get(key)
+    if addr is None:
+        dkey = str(t.device)
+        slab = _tile_slabs.get(dkey)
+        if slab is None:
+            if t.is_cuda and torch.cuda.is_current_stream_capturing():
+                return None
+            slab = prepare_tile_counters(t.device)
+        with _tile_lock:
+            n = sum(1 for k in _tile_blocks if k[1] == dkey)
+            if n >= _TILE_SLAB_BLOCKS:
+                return None
+            addr = _tile_blocks[key] = slab.data_ptr() + 64 * n
+    return addr
+
+
+def _tileloop_wanted(M, N, K, share):
+    """measured policy (profiles/r06_tileloop.md): the wide-N short-K Linear layers and whatever has several rounds of tiles"""
+    if M < 2048 or N % 320 or K < 256:
+        return False
+    tiles = ((M + 255) // 256) * (N // 320)
+    return N >= 3840 and K <= 2560 and tiles >= 256
+
+
+def gemm_tileloop(a, w, *, a2=None, bias=None, residual=None, out=None, alpha=1.0, rows_per_batch=0, geglu=False,
+                  dynamic=True, strict_order=False, max_wg=0):
+    """`gemm` (DENSE) on the persistent tile loop: out = alpha * [a | a2] . w^T + bias + residual, bit-identical to the
+    256x320 kernel of mc_gemm_f16.  Returns None when the shape is outside the kernel (caller: `gemm`)."""
+    _f16(a), _f16(w)
+    N, K = w.shape
+    M, c1 = a.shape
+    assert c1 + (a2.shape[1] if a2 is not None else 0) == K
+    n_out = N // 2 if geglu else N
+    if out is None:
+        out = empty((M, n_out), a)
+    assert out.shape[0] == M and out.shape[1] == n_out
+    if bias is not None:
+        _f32(bias)
+        assert bias.shape[-1] == N
+    st = _stream(a)
+    ctr = _tile_counter_block(a, st) if dynamic else None
+    flags = (0x200 if geglu else 0) | (1 if strict_order else 0) | ((max_wg // 8) << 16)
+    ok = lib.try_call("mc_gemm_tileloop_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
+                      _ld(a2), _ld(out), _ld(residual), c1, rows_per_batch, float(alpha), flags, ctr, 64 if ctr else 0, st)
+    return out if ok else None
+
+
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
          rows_per_batch=0, tile=0, m_out=None, geglu=False, deep=False, cfg=0, splits=None,
-         pad_front=True, nsplit=0, g3_splitk=False):
+         pad_front=True, nsplit=0, g3_splitk=False, tileloop=None):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
 
     geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
@@ -138,6 +213,13 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
     share = gemm_share()
+    if tileloop is None:
+        tileloop = TILELOOP
+    if mode == DENSE and not (tile or deep or cfg or g3_splitk) and (splits is None or splits == 1) and tileloop is not False \
+            and (tileloop or _tileloop_wanted(M, N, K, share)):
+        if gemm_tileloop(a, w, a2=a2, bias=bias, residual=residual, out=out, alpha=alpha, rows_per_batch=rows_per_batch,
+                         geglu=geglu) is not None:
+            return out
     flags = tile | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
         | (0 if pad_front else 0x800) | (nsplit << 16) | (share << 20) | (0x1000000 if g3_splitk else 0)
     if bias is not None:

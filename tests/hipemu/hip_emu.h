@@ -288,3 +288,7 @@ inline float atomicAdd(float* p, float v) {
     }
     return old;
 }
+inline uint32_t atomicAdd(uint32_t* p, uint32_t v) {
+    std::atomic_ref<uint32_t> r(*p);
+    return r.fetch_add(v);
+}

@@ -117,6 +117,43 @@ def test_gemm5_ring_kernel(backend, var):
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm5 geglu")
 
 
+@pytest.mark.parametrize("dynamic", [False, True])
+def test_gemm6_persistent_tile_loop_equals_gemm5_bit_for_bit(backend, dynamic):
+    """gemm6.hip (mc_gemm_tileloop_f16: one workgroup per CU walks the 256x320 tiles, the operand ring runs through tile
+    boundaries, epilogue through 32 x 80 images in the free ring slot): outputs EQUAL gemm5's (one fp32 chain per element in the
+    same order) - plain, bias, bias + residual, fused GEGLU, M / N tails, several tiles per workgroup (grid cap), static and
+    dynamic tile order, both vmcnt variants; vs fp32 torch; the counter block is zero again after every launch."""
+    dev = backend
+    shapes = [(2100, 648, 320, 16), (2304, 960, 256, 8)] if not big(dev) else [(8192, 3840, 1280, 0), (9000, 1928, 640, 64), (32768, 1280, 256, 0)]
+    for (M, N, K, cap) in shapes:
+        a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+        bias = torch.randn(1, N, generator=torch.Generator().manual_seed(3)).to(dev)
+        res = rnd((M, N), dev, 4)
+        for (b, r) in [(None, None), (bias, None), (bias, res)]:
+            ref = ops.gemm(a, w, bias=b, residual=r, alpha=0.5, cfg=11)
+            for strict in (False, True):
+                out = torch.full_like(ref, float("nan"))
+                got = ops.gemm_tileloop(a, w, bias=b, residual=r, alpha=0.5, out=out, dynamic=dynamic, strict_order=strict, max_wg=cap)
+                assert got is not None, "shape refused"
+                assert torch.equal(out, ref), "tile loop differs from gemm5: %d %d %d bias %s res %s" % (M, N, K, b is not None, r is not None)
+            lin = 0.5 * (a.float() @ w.float().t()) + (b if b is not None else 0)
+            close(out, lin.half().float() + (r.float() if r is not None else 0), 2e-2, 5e-3, "tile loop vs fp32")
+        if N % 16 == 0:
+            wg = ops.interleave_geglu(rnd((N, K), dev, 8, 0.1))
+            bg = ops.interleave_geglu(torch.randn(N, generator=torch.Generator().manual_seed(9))).unsqueeze(0).to(dev)
+            ref = ops.gemm(a, wg, bias=bg, geglu=True, cfg=11)
+            out = torch.full_like(ref, float("nan"))
+            assert ops.gemm_tileloop(a, wg, bias=bg, geglu=True, out=out, dynamic=dynamic, max_wg=cap) is not None
+            assert torch.equal(out, ref), "tile loop GEGLU differs from gemm5"
+    for slab in ops._tile_slabs.values():
+        assert int(slab.count_nonzero()) == 0, "a launch left its tile counters dirty"
+    # outside the kernel's shapes: refused, nothing launched
+    a, w = rnd((1024, 256), dev, 1), rnd((640, 256), dev, 2)
+    assert ops.gemm_tileloop(a, w) is None                      # fewer than 8 row tiles
+    a, w = rnd((2048, 128), dev, 1), rnd((640, 128), dev, 2)
+    assert ops.gemm_tileloop(a, w) is None                      # K < 256
+
+
 @pytest.mark.parametrize("mode", ["s2", "up", "tconv"])
 def test_gemm5_conv_modes(backend, mode):
     dev = backend
