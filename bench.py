@@ -396,6 +396,9 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="videos batched into ONE launch sequence per lane (latents [V, ...], text "
                     "[u_1 .. u_V | c_1 .. c_V]: the same kernels on V times the rows); --inflight lanes x --batch videos are in "
                     "flight together.  --steps must be a multiple of it")
+    ap.add_argument("--tileloop", choices=["auto", "off", "all"], default="auto", help="A/B: the persistent tile loop (gemm6.hip) for the "
+                    "dense 256x320-tile layers: auto = the library's measured policy, off = never (round 5's kernels), all = every "
+                    "shape the kernel accepts")
     ap.add_argument("--inflight", type=int, default=3, help="independent videos processed concurrently per GPU (own HIP stream, "
                     "own sampler / graphs each).  At config 2: 2 in flight +8-10 %% videos/min over one (kernel tails and the "
                     "small 16x16 / 8x8-level kernels of one video are filled by the others), 3 in flight another +2.6 %%, 4 lose; "
@@ -422,6 +425,7 @@ def main():
     lib.load()  # fails loudly if the gfx950 library is missing
     if args.no_norm_fusion:
         ops.NORM_GEMM_MIN_ROWS = 1 << 62
+    ops.TILELOOP = {"auto": None, "off": False, "all": True}[args.tileloop]
 
     cfg = default_config()
     total = sum(int(torch.Size(s).numel()) for s in spec.param_shapes(cfg).values())

@@ -67,17 +67,23 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
 
 /* Persistent tile loop over the 256x320 tile (gemm6.hip, round 6): the same product as mc_gemm_f16 (DENSE, bit-identical to
  * its 256x320 kernel) with ONE workgroup per CU walking the output tiles and the LDS operand ring running through tile
- * boundaries - for the wide-N short-K Linear layers (diffusers FeedForward's first Linear at attention.py:211,288 /
- * motion_module.py:209,222; to_q|k|v at attention.py:355-357), where a tile's fixed cost is a third of its k-loop.
- *   workspace: mc_workspace_bytes_gemm_tileloop() bytes, ZERO at kernel start: per-XCD tile counters of the dynamic tile order;
- *     the kernel zeroes them again before it ends (no memset per launch; launches that may overlap need separate blocks);
- *     null = static tile order.
- *   flags: 0x200 fused GEGLU; 0x1 A/B: drain the epilogue's stores before the next tile's first wait; bits 16-23 grid cap / 8.
- * Returns MC_ERR_UNSUPPORTED (-2) outside its shapes (K < 256, M < 1793, N % 8): call mc_gemm_f16. */
-long mc_workspace_bytes_gemm_tileloop(void);
+ * boundaries - for the Linear layers (diffusers FeedForward at attention.py:211,288 / motion_module.py:209,222; to_q|k|v and
+ * to_out at attention.py:355-364; proj_in / proj_out at attention.py:65,93 and motion_module.py:113,135), where a tile's fixed
+ * cost was up to a third of its k-loop.
+ *   workspace: mc_workspace_bytes_gemm_tileloop(0) bytes, ZERO at kernel start: per-XCD tile counters of the dynamic tile order
+ *     and the hand-over flags of stream-K; the kernel zeroes them again before it ends (no memset per launch; launches that may
+ *     overlap need separate blocks); null = static tile order.
+ *   partials: mc_workspace_bytes_gemm_tileloop(1) bytes of scratch, flags 0x2 (stream-K) only: the k-stages of each XCD's tile
+ *     list are dealt evenly to its workgroups, tiles are cut along k where a range ends, the later pieces' fp32 sums meet the
+ *     first piece's here (replaces split-K + reduce; a cut tile's sum is deterministic but not the one-chain sum).
+ *   flags: 0x200 fused GEGLU; 0x2 stream-K; 0x1 A/B: drain the epilogue's stores before the next tile's first wait;
+ *     bits 16-23 grid cap / 8.
+ * Returns MC_ERR_UNSUPPORTED (-2) outside its shapes (K < 256, N % 8, two-source A, per-batch bias, M < 1793 without
+ * stream-K): call mc_gemm_f16. */
+long mc_workspace_bytes_gemm_tileloop(int which);
 int mc_gemm_tileloop_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                          int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int rows_per_batch, float alpha,
-                         int flags, void* workspace, size_t ws_bytes, void* stream);
+                         int flags, void* workspace, size_t ws_bytes, void* partials, size_t partial_bytes, void* stream);
 
 /* PROFILING ONLY: the kernel structure used by the calling thread's last mc_gemm_f16 / mc_gemm_splitk_f16 call:
  * 2 / 20 = gemm2 128x128 / 64x64 tiles, 31..35 = gemm3 geometry 1..5, 4 = gemm4, 51 / 54 = gemm5 with 256- / 128-row tiles;

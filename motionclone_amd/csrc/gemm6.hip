@@ -43,11 +43,25 @@ constexpr int BSTRIP = 640;                      // one wave's bias strip: 160 f
 constexpr int TAIL = 2 * IMG + 4 * BSTRIP;       // behind the ring: images of waves 6-7, bias strips of waves 4-7
 constexpr size_t SMEM = T::SMEM + TAIL + 16;     // ... and the tile hand-over word
 constexpr int NK_MIN = 8;                        // stages per tile the schedule assumes at least (K >= 256)
+constexpr int PMIN = 8;                          // stream-K: stages a piece of a tile has at least
+constexpr int SLAB_FLOATS = 256 * 320;           // one workgroup's accumulators
+constexpr int FLAG0 = 16;                        // first "partial sums ready" word of the counter block
+constexpr int CTR_WORDS = 512;                   // counter block: 2 KiB
 static_assert(IMG_IN_SLOT * IMG + 4 * BSTRIP <= T::STAGE && SMEM <= 160 * 1024, "epilogue images: one ring slot + the tail");
 
 // local index `l` of XCD `xcd`'s tile list -> (tm, tn); false past the end.  Rows of the XCD: tm = 8 i + xcd, walked in groups
 // of sm rows, inside a group in column blocks of sn tiles, rows fastest (gemm5's super-tile order without holes).
-__device__ __forceinline__ bool tile_of(int l, int xcd, int tilesM, int tilesN, int sm, int sn, int& tm, int& tn) {
+__device__ __forceinline__ int list_len(int xcd, int tilesM, int tilesN, int flat) {
+    return flat ? (tilesM * tilesN - xcd + 7) >> 3 : ((tilesM - xcd + 7) >> 3) * tilesN;
+}
+__device__ __forceinline__ bool tile_of(int l, int xcd, int tilesM, int tilesN, int sm, int sn, int flat, int& tm, int& tn) {
+    if (flat) {
+        const int f = 8 * l + xcd;
+        if (l < 0 || f >= tilesM * tilesN) return false;
+        tn = f / tilesM;
+        tm = f - tn * tilesM;
+        return true;
+    }
     const int rows = (tilesM - xcd + 7) >> 3;
     if (l >= rows * tilesN) return false;
     const int per_group = sm * tilesN;
@@ -58,6 +72,16 @@ __device__ __forceinline__ bool tile_of(int l, int xcd, int tilesM, int tilesN, 
     tm = (g * sm + w % rg) * 8 + xcd;
     return true;
 }
+// stream-K: first stage of range r (0 .. n) when the S stages of an XCD's list are dealt to n workgroups.  A boundary that would
+// leave a piece of fewer than PMIN stages on either side of it moves to the tile boundary (the k-loop's look-ahead assumes
+// PMIN stages per piece).
+__device__ __forceinline__ int sk_bound(int r, int n, int S, int nk) {
+    int b = (int)((long)r * S / n);
+    const int rem = b % nk;
+    if (rem < PMIN) b -= rem;
+    else if (nk - rem < PMIN) b += nk - rem;
+    return b;
+}
 }  // namespace g6
 
 // Everything the kernel is told, in ONE by-value block: the parts only the epilogue / the tile switch read are fetched there
@@ -67,7 +91,11 @@ struct G6Args {
     GemmParams p;
     uint32_t bytesA, bytesW, bytesC, bytesR, bytesB;
     int tilesM, tilesN, sm, sn;
-    uint32_t* ctr;
+    int mode;          // 0 static tile order, 1 dynamic (per-XCD counters), 2 stream-K (stage ranges, tiles may be cut along k)
+    int flat;          // tile lists without super-tiles (fewer than 8 rows of tiles): list entry l of XCD x = tile 8 l + x, rows fastest
+    uint32_t* ctr;     // words 0-7 tile counters, 8 arrival count, 16 + 32 x + r: "partial sums of range r of XCD x are in memory"
+    float* slabs;      // stream-K: [8][32] fp32 accumulator images (256 x 320 each)
+    uint32_t bytesS;
 };
 #ifdef MC_EMU
 #define MC_SCHED_FENCE() ((void)0)
@@ -117,6 +145,31 @@ __device__ __forceinline__ uint32_t lds_ld32(const char* p) {
 __device__ __forceinline__ void lds_st32(char* p, uint32_t v) {
     const uint32_t a = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) char*)p;
     asm volatile("ds_write_b32 %0, %1" ::"v"(a), "v"(v) : "memory");
+}
+#endif
+
+// stream-K hand-over primitives: 16-byte buffer store / load that bypass the non-coherent levels (sc1: write-through / L2-served),
+// and a device-scope flag
+#ifdef MC_EMU
+__device__ inline void gbuf_st16_wt(GBuf b, uint32_t voff, f32x4 v) { gbuf_st8(b, voff, __builtin_bit_cast(half8_t, v)); }
+__device__ inline f32x4 gbuf_ld16_wt(GBuf b, uint32_t voff) { return __builtin_bit_cast(f32x4, gbuf_ld8(b, voff)); }
+__device__ inline void flag_store(uint32_t* f, uint32_t v) { std::atomic_ref<uint32_t>(*f).store(v, std::memory_order_release); }
+__device__ inline void flag_wait(uint32_t* f) {
+    while (std::atomic_ref<uint32_t>(*f).load(std::memory_order_acquire) == 0) std::this_thread::yield();
+}
+#else
+__device__ __forceinline__ void gbuf_st16_wt(GBuf b, uint32_t voff, f32x4 v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), b, (int)voff, 0, 16);   // aux 16 = sc1
+}
+__device__ __forceinline__ f32x4 gbuf_ld16_wt(GBuf b, uint32_t voff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(b, (int)voff, 0, 16));
+}
+__device__ __forceinline__ void flag_store(uint32_t* f, uint32_t v) {
+    __hip_atomic_store(f, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void flag_wait(uint32_t* f) {
+    while (__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) __builtin_amdgcn_s_sleep(4);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 #endif
 
@@ -229,7 +282,7 @@ __device__ __forceinline__ void g6_epilogue(const G6Args* ap, f32x16 (&acc)[g5::
     }
 }
 
-template <int EPI, int RES, int VAR>
+template <int EPI, int RES, int VAR, int SK>
 __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
     using g5::TN; using g5::BKT; using g5::RPI; using g5::lds_off32;
     using T = g6::T;
@@ -248,9 +301,13 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 #endif
     const bool grpA = wave < WX;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslots = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7, nslots = gridDim.x >> 3;
     const int nk = args.p.K / BKT;
-    const bool dynamic = args.ctr != nullptr;
+    constexpr bool sk = SK != 0;     // stream-K is its own instantiation: its hand-over code costs the other modes registers
+    const bool dynamic = !sk && args.mode == 1;
+    // stream-K deals the ranges in REVERSE dispatch order: the workgroup that finishes a cut tile (it owns the tile's first
+    // stages, at the END of its range) waits for workgroups with LOWER block indices, which were dispatched before it
+    const int slot = sk ? nslots - 1 - (int)(blockIdx.x >> 3) : (int)(blockIdx.x >> 3);
     char* handover = smem + T::SMEM + g6::TAIL;
 
     const GBuf bufA = make_gbuf(args.p.A, args.bytesA);
@@ -290,7 +347,7 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
     auto setup_tile = [&](int local) {   // scalar part
         const g6args_t q = late(G6_ARGS);
         int tm = 0, tn = 0;
-        l_valid = g6::tile_of(local, xcd, q->tilesM, q->tilesN, q->sm, q->sn, tm, tn);
+        l_valid = g6::tile_of(local, xcd, q->tilesM, q->tilesN, q->sm, q->sn, q->flat, tm, tn);
         l_m0 = tm * BM;
         l_n0 = tn * BN;
     };
@@ -309,11 +366,25 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
     // ---- work list ----------------------------------------------------------------------------------------------------------
     int t_load = slot;
     int t_next = slot + nslots;          // static order; dynamic: replaced by the counter's answers
+    int lkt = 0, l_kend = nk;            // next k-stage of the load tile / end of the piece being loaded
+    int r_end = 0;                       // stream-K: end of this workgroup's range, in stages of its XCD's list
+    if (sk) {
+        const g6args_t q = late(G6_ARGS);
+        const int S = g6::list_len(xcd, q->tilesM, q->tilesN, q->flat) * nk;
+        const int r_beg = g6::sk_bound(slot, nslots, S, nk);
+        r_end = g6::sk_bound(slot + 1, nslots, S, nk);
+        if (r_beg >= r_end) return;      // (nothing to reset: stream-K keeps no counters)
+        t_load = r_beg / nk;
+        lkt = r_beg - t_load * nk;
+        l_kend = min(nk, r_end - t_load * nk);
+    }
     setup_tile(t_load);
     if (!l_valid) {
         leave();
         return;
     }
+    int c_kbeg = lkt, c_cnt = l_kend - lkt;   // the piece being multiplied: first k-stage, stages
+    int n_cnt = nk;                           // ... and the stages of the one being loaded, once the load side has moved on
     // dynamic order: the second tile's index is requested now and handed over after the prologue's wait (which covers it:
     // vmcnt retires in issue order and the request is older than every operand load)
     uint32_t ticket = 0;
@@ -332,7 +403,6 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
 
     const int wr = wave % WMW, wc = wave / WMW;
     const int wm0 = wr * (32 * TM), wn0 = wc * 160;
-    int lkt = 0;                         // next k-stage of the load tile
 
     half8_t fa[2][TM], fw[2][TN];
     int l31 = 0, lhi = 0;            // set right before their first use and again after every epilogue: nothing lane-derived
@@ -391,11 +461,80 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
             t_next = __builtin_amdgcn_readfirstlane((int)v);
 #endif
         }
-        t_load = t_next;
-        setup_tile(t_load);
+        if (sk) {
+            t_load += 1;                 // the next tile of the list, as far as the range reaches into it
+            setup_tile(t_load);
+            l_valid = l_valid && t_load * nk < r_end;
+            l_kend = min(nk, r_end - t_load * nk);
+        } else {
+            t_load = t_next;
+            setup_tile(t_load);
+            t_next = t_load + nslots;    // (static order)
+        }
         setup_offsets();
         lkt = 0;
-        t_next = t_load + nslots;        // (static order)
+        n_cnt = l_kend;
+    };
+
+    // ---- stream-K hand-over of partial sums --------------------------------------------------------------------------------
+    // Slab of range r of XCD x: accumulator-native order, chunk (i, j, q) of lane l of wave w at float4 index
+    // ((w 20 TM + (i TM + j) 4 + q) 64 + l: every instruction moves 1 KiB contiguously.  Producer: write-through (sc1) stores,
+    // each wave waits for its own (vmcnt(0)), workgroup barrier, ONE lane stores the flag (device scope).  Consumer: ONE lane
+    // polls the flag (relaxed, device scope) and runs the device-scope acquire, workgroup barrier, sc1 loads
+    // (MI355X_MICROARCH.md: inter-workgroup visibility).  The consumer clears the flag: the block is zero again when the kernel ends.
+    auto slab_voff = [&](int range) {
+        return (uint32_t)((xcd * 32 + range) * (g6::SLAB_FLOATS / 4) + wave * (TN * TM * 4 * 64) + lane_now()) * 16u;
+    };
+    auto store_partial = [&]() {
+        const g6args_t q = late(G6_ARGS);
+        const GBuf bufS = make_gbuf(q->slabs, q->bytesS);
+        const uint32_t base = slab_voff(slot);
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+#pragma unroll
+                for (int qq = 0; qq < 4; ++qq) {
+                    f32x4 v;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * qq + e];
+                    gbuf_st16_wt(bufS, base + (uint32_t)(((i * TM + j) * 4 + qq) * 64) * 16u, v);
+                }
+    };
+    auto raise_flag = [&]() {
+        if (wave == 0 && lane_now() == 0)
+            flag_store(late(G6_ARGS)->ctr + g6::FLAG0 + xcd * 32 + slot, 1u);
+    };
+    auto gather_partials = [&](int k_have) {
+        const g6args_t q = late(G6_ARGS);
+        const GBuf bufS = make_gbuf(q->slabs, q->bytesS);
+        const int S = g6::list_len(xcd, q->tilesM, q->tilesN, q->flat) * nk;
+        const int tile_end = (r_end / nk + 1) * nk;       // this piece starts its tile: the tile is the one r_end lies in
+        (void)k_have;
+        for (int r = slot + 1; r < nslots && g6::sk_bound(r, nslots, S, nk) < tile_end; ++r) {
+            uint32_t* flag = q->ctr + g6::FLAG0 + xcd * 32 + r;
+            if (wave == 0 && lane_now() == 0) {
+                flag_wait(flag);
+                flag_store(flag, 0u);
+            }
+            raw_barrier();
+            const uint32_t base = slab_voff(r);
+            // (compile-time indices through static_for: with `#pragma unroll` loops inside this run-time loop hipcc kept the
+            // accumulator array in scratch memory)
+            static_for<TN>([&](auto ic) {
+                static_for<TM>([&](auto jc) {
+                    constexpr int i = decltype(ic)::value, j = decltype(jc)::value;
+                    const f32x4 v0 = gbuf_ld16_wt(bufS, base + (uint32_t)(((i * TM + j) * 4 + 0) * 64) * 16u);
+                    const f32x4 v1 = gbuf_ld16_wt(bufS, base + (uint32_t)(((i * TM + j) * 4 + 1) * 64) * 16u);
+                    const f32x4 v2 = gbuf_ld16_wt(bufS, base + (uint32_t)(((i * TM + j) * 4 + 2) * 64) * 16u);
+                    const f32x4 v3 = gbuf_ld16_wt(bufS, base + (uint32_t)(((i * TM + j) * 4 + 3) * 64) * 16u);
+                    acc[i][j][0] += v0[0]; acc[i][j][1] += v0[1]; acc[i][j][2] += v0[2]; acc[i][j][3] += v0[3];
+                    acc[i][j][4] += v1[0]; acc[i][j][5] += v1[1]; acc[i][j][6] += v1[2]; acc[i][j][7] += v1[3];
+                    acc[i][j][8] += v2[0]; acc[i][j][9] += v2[1]; acc[i][j][10] += v2[2]; acc[i][j][11] += v2[3];
+                    acc[i][j][12] += v3[0]; acc[i][j][13] += v3[1]; acc[i][j][14] += v3[2]; acc[i][j][15] += v3[3];
+                });
+            });
+        }
     };
 
     auto run = [&](auto ga_tag) {
@@ -442,9 +581,10 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
         }
         load_frags(0, 0, fa[0], fw[0]);
         int k = 0;
+        bool finish = false;
         for (;;) {
-            for (; k < nk - 1; ++k) {
-                if (lkt == nk) advance();
+            for (; k < c_cnt - 1; ++k) {
+                if (lkt == l_kend) advance();
                 stage(X0());
             }
             // the tile's last stage, with the wave's 160 bias values requested in front of it (one more load in the queue:
@@ -470,11 +610,33 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
             // epilogue (every wave read the previous hand-over word three barriers ago)
             const bool ask = dynamic && wave == 0 && l_valid && lane_now() == 0;
             if (ask) ticket = atomicAdd(late(G6_ARGS)->ctr + xcd, 1u);
-            g6_epilogue<EPI, RES, TM>(G6_ARGS, acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
+            if (sk && c_kbeg > 0) {
+                // stream-K, a piece that does not start its tile: the accumulators go to this range's slab (write-through
+                // stores, every wave waits for its own), then one lane raises the range's flag.  No epilogue: the workgroup
+                // that owns the tile's first stages adds the slab to its own sums.  (vmcnt(0) also retires the ring's loads:
+                // the relaxed waits of the next two stages are trivially met.)
+                store_partial();
+                wait_vmcnt_le<0>();
+                raw_barrier();
+                raise_flag();
+            } else {
+                if (sk && c_cnt < nk) {
+                    // stream-K, the piece that STARTS a cut tile (always the last piece of a range): the tile's later stages
+                    // were multiplied elsewhere.  Their sums are added, and the epilogue run, BEHIND the loop: with the
+                    // gathering loop in here hipcc's register allocation of the whole k-loop collapsed (136 dwords of scratch)
+                    // (nothing a vector-memory load produced may live out of the loop - bias4 included: it would be a pending
+                    // load at the loop header, i.e. an s_waitcnt vmcnt(0) in every k-step)
+                    finish = true;
+                    break;
+                }
+                g6_epilogue<EPI, RES, TM>(G6_ARGS, acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
+            }
             if (!l_valid) break;            // the load side ran off the list: nothing real is in flight
             if (ask) lds_st32(handover, (uint32_t)nslots + ticket);
             c_m0 = l_m0;
             c_n0 = l_n0;
+            c_kbeg = 0;
+            c_cnt = n_cnt;
             zero_acc();
             {
                 const int ln = lane_now();
@@ -489,22 +651,41 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
             stage(XS());
             k = 2;
         }
+        if (sk && finish) {
+            const int freed = slot_of_new(buf);
+            char* img = wave < g6::IMG_IN_SLOT ? smem + freed * STAGE + wave * g6::IMG
+                                               : smem + T::SMEM + (wave - g6::IMG_IN_SLOT) * g6::IMG;
+            char* bstrip = wave < 4 ? smem + freed * STAGE + g6::IMG_IN_SLOT * g6::IMG + wave * g6::BSTRIP
+                                    : smem + T::SMEM + 2 * g6::IMG + (wave - 4) * g6::BSTRIP;
+            gather_partials(c_cnt);
+            f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+            const g6args_t q = late(G6_ARGS);
+            if (q->p.bias) {
+                const GBuf bufB = make_gbuf(q->p.bias, q->bytesB);
+                const int ln = lane_now(), n = c_n0 + wn0 + 4 * ln;
+                bias4 = __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < 40 && n < q->p.N) ? (uint32_t)n * 4u : kOOB));
+            }
+            g6_epilogue<EPI, RES, TM>(G6_ARGS, acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
+        }
     };
     if (grpA) run(std::true_type()); else run(std::false_type());
     wait_vmcnt_le<0>();   // the zero-fill loads issued past the end of the list still write this workgroup's LDS
     leave();
 }
 
-template <int EPI, int RES, int VAR>
-static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t* ctr, int max_wg, hipStream_t stream) {
+// mode: 0 static, 1 dynamic (ctr), 2 stream-K (ctr + slabs)
+template <int EPI, int RES, int VAR, int SK>
+static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, int mode, uint32_t* ctr, float* slabs, int max_wg,
+                   hipStream_t stream) {
     constexpr int BM = 256, BN = g5::BN;
-    const int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
-    allow_big_smem(gemm6_kernel<EPI, RES, VAR>, g6::SMEM);
+    const int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN, nk = p.K / g5::BKT;
+    allow_big_smem(gemm6_kernel<EPI, RES, VAR, SK>, g6::SMEM);
     // super-tile of the XCD-local order: as launch5 (sm x sn ~ the 32 workgroups of an XCD, least operand rows per tile)
     const int rows_per_xcd = (tM + 7) / 8;
+    const int flat = tM < 8;
     int sm = 1, sn = 1;
     const bool w_resident = (size_t)p.N * p.K * 2 <= (size_t)3 << 20;
-    if (!w_resident) {
+    if (!w_resident && !flat) {
         long best = -1;
         for (int c = 1; c <= tN && c <= 16; ++c) {
             if (tN % c) continue;
@@ -513,8 +694,15 @@ static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t* ctr,
             if (best < 0 || cost < best) best = cost, sm = r, sn = c;
         }
     }
-    // workgroups per XCD: one per CU, no more than the longest per-XCD list
-    int nslots = std::min(32, rows_per_xcd * tN);
+    // workgroups per XCD: one per CU, no more than the longest per-XCD list (stream-K: than its stages / 2 PMIN)
+    int longest = 0, shortest = 1 << 30;
+    for (int x = 0; x < 8; ++x) {
+        const int len = flat ? (tM * tN - x + 7) / 8 : ((tM - x + 7) / 8) * tN;
+        longest = std::max(longest, len);
+        if (len > 0) shortest = std::min(shortest, len);
+    }
+    int nslots = std::min(32, longest);
+    if (mode == 2) nslots = std::max(1, std::min(32, shortest * nk / (2 * g6::PMIN)));
     if (max_wg > 0) nslots = std::max(1, std::min(nslots, max_wg / 8));
     const size_t outc = p.epi ? (size_t)p.N / 2 : (size_t)p.N;
     const size_t bytesC = ((size_t)(p.M - 1) * p.ldc + outc) * 2, bytesR = p.R ? ((size_t)(p.M - 1) * p.ldr + outc) * 2 : 0;
@@ -524,15 +712,22 @@ static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, uint32_t* ctr,
     a.bytesA = bA; a.bytesW = bW; a.bytesC = (uint32_t)bytesC; a.bytesR = (uint32_t)bytesR;
     a.bytesB = p.bias ? (uint32_t)p.N * 4u : 0u;
     a.tilesM = tM; a.tilesN = tN; a.sm = sm; a.sn = sn;
-    a.ctr = ctr;
-    MC_LAUNCH((gemm6_kernel<EPI, RES, VAR>), dim3((unsigned)(8 * nslots)), dim3(512), g6::SMEM, stream, a);
+    a.mode = mode; a.flat = flat;
+    a.ctr = ctr; a.slabs = slabs;
+    a.bytesS = mode == 2 ? (uint32_t)(8u * 32u * g6::SLAB_FLOATS * 4u) : 0u;
+    MC_LAUNCH((gemm6_kernel<EPI, RES, VAR, SK>), dim3((unsigned)(8 * nslots)), dim3(512), g6::SMEM, stream, a);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
+size_t gemm6_slab_bytes() { return (size_t)8 * 32 * g6::SLAB_FLOATS * 4; }
+size_t gemm6_counter_bytes() { return (size_t)g6::CTR_WORDS * 4; }
+
 // Persistent tile loop for DENSE problems (one activation source, one bias row).  var bit 0: drain the epilogue's stores at
-// the first k-step (no in-order assumption between stores and loads).  ctr: 9 zeroed 32-bit words (dynamic tile order) or null
-// (static).  max_wg: cap on the grid (0 = one workgroup per CU).  MC_ERR_UNSUPPORTED for what stays on gemm5 / gemm3.
-int gemm6_dispatch(const GemmParams& p, int var, uint32_t* ctr, int max_wg, hipStream_t stream) {
+// the first k-step (no in-order assumption between stores and loads).  mode 0: static tile order; 1: dynamic (ctr: zeroed
+// counter block); 2: stream-K (ctr + slabs: the stages of every XCD's tile list are dealt evenly, tiles are cut along k where
+// a range ends, partial sums meet in `slabs`).  max_wg: cap on the grid (0 = one workgroup per CU).  MC_ERR_UNSUPPORTED for what
+// stays on gemm5 / gemm3.
+int gemm6_dispatch(const GemmParams& p, int var, int mode, uint32_t* ctr, float* slabs, int max_wg, hipStream_t stream) {
     const size_t bytesA = ((size_t)p.M * (size_t)p.lda) * 2;
     const size_t bytesW = (size_t)p.N * p.K * 2;
     const size_t lim = 0x7FFFFFF0u;
@@ -543,13 +738,15 @@ int gemm6_dispatch(const GemmParams& p, int var, uint32_t* ctr, int max_wg, hipS
     if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
     if (p.K / g5::BKT < g6::NK_MIN) return MC_ERR_UNSUPPORTED;
     if (p.epi == 1 && ((p.N & 15) || p.R)) return MC_ERR_UNSUPPORTED;
-    if ((p.M + 255) / 256 < 8) return MC_ERR_UNSUPPORTED;     // every XCD owns at least one row of tiles
-    if (p.epi == 1) return (var & 1) ? launch6<1, 0, 1>(p, bytesA, bytesW, ctr, max_wg, stream)
-                                     : launch6<1, 0, 0>(p, bytesA, bytesW, ctr, max_wg, stream);
-    if (p.R) return (var & 1) ? launch6<0, 1, 1>(p, bytesA, bytesW, ctr, max_wg, stream)
-                              : launch6<0, 1, 0>(p, bytesA, bytesW, ctr, max_wg, stream);
-    return (var & 1) ? launch6<0, 0, 1>(p, bytesA, bytesW, ctr, max_wg, stream)
-                     : launch6<0, 0, 0>(p, bytesA, bytesW, ctr, max_wg, stream);
+    if (mode != 2 && (p.M + 255) / 256 < 8) return MC_ERR_UNSUPPORTED;     // every XCD owns at least one row of tiles
+    if ((mode == 1 && !ctr) || (mode == 2 && (!ctr || !slabs)) || mode < 0 || mode > 2) return MC_ERR_SHAPE;
+#define MC_G6A(E, R, V, S) launch6<E, R, V, S>(p, (uint32_t)bytesA, (uint32_t)bytesW, mode, ctr, slabs, max_wg, stream)
+#define MC_G6(E, R) (mode == 2 ? MC_G6A(E, R, 0, 1) : (var & 1) ? MC_G6A(E, R, 1, 0) : MC_G6A(E, R, 0, 0))
+    if (p.epi == 1) return MC_G6(1, 0);
+    if (p.R) return MC_G6(0, 1);
+    return MC_G6(0, 0);
+#undef MC_G6
+#undef MC_G6A
 }
 
 }  // namespace mc

@@ -14,7 +14,9 @@ int gemm3_dispatch(const GemmParams& p, int mode, int cfg, size_t rowsA, hipStre
 int gemm4_dispatch(const GemmParams& p, int nsplit, hipStream_t stream, const G4Norm* norm = nullptr);          // gemm4.hip
 int gemm4_check(const GemmParams& p, const G4Norm* norm);                                                        // gemm4.hip
 int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStream_t stream);                    // gemm5.hip
-int gemm6_dispatch(const GemmParams& p, int var, uint32_t* ctr, int max_wg, hipStream_t stream);                 // gemm6.hip
+int gemm6_dispatch(const GemmParams& p, int var, int mode, uint32_t* ctr, float* slabs, int max_wg, hipStream_t stream);   // gemm6.hip
+size_t gemm6_slab_bytes();
+size_t gemm6_counter_bytes();
 int gn_partial_launch(const void* a, int lda, int ctot, int frames, int hw, float* partial, hipStream_t stream);   // norm.hip
 }  // namespace mc
 
@@ -245,26 +247,39 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
 // ---- persistent tile loop (round 6, gemm6.hip) ---------------------------------------------------------------------------
 // C[M,N] = alpha * A[M,K] . W[N,K]^T + bias + R (or the fused GEGLU epilogue) with ONE workgroup per CU walking the 256x320
 // tiles: the operand ring runs through tile boundaries, so the three-stage prologue burst is paid once per launch instead
-// of once per tile.  Same arithmetic as mc_gemm_f16's 256x320 kernel (bit-identical outputs).
-//   workspace / ws_bytes: >= mc_workspace_bytes_gemm_tileloop() bytes that are ZERO when the kernel starts: the per-XCD tile
-//     counters of the dynamic tile order.  The kernel leaves them zero again, so one zero-initialised block serves every
-//     launch of a stream (and every replay of a captured graph) without a memset; launches that may run CONCURRENTLY need
-//     separate blocks.  workspace == null: static tile order (workgroup b walks tiles b, b + grid, ...).
+// of once per tile.  Same arithmetic as mc_gemm_f16's 256x320 kernel (bit-identical outputs unless a tile is cut, below).
+//   workspace / ws_bytes: >= mc_workspace_bytes_gemm_tileloop(0) bytes that are ZERO when the kernel starts: the per-XCD tile
+//     counters of the dynamic tile order and the hand-over flags of stream-K.  The kernel leaves them zero again, so one
+//     zero-initialised block serves every launch of a stream (and every replay of a captured graph) without a memset;
+//     launches that may run CONCURRENTLY need separate blocks.  workspace == null: static tile order (workgroup b walks
+//     tiles b, b + grid, ...).
+//   partials / partial_bytes (flags 0x2, stream-K): mc_workspace_bytes_gemm_tileloop(1) bytes of scratch (any contents).  The
+//     k-stages of every XCD's tile list are dealt evenly to its workgroups; where a range ends inside a tile the tile is cut
+//     along k, the later pieces leave their fp32 sums in `partials` and the workgroup that owns the tile's first stages adds
+//     them in k order and runs the epilogue - what split-K + reduce did in two launches, without the quantisation of whole
+//     tiles per workgroup.  A cut tile's sum is (first piece) + (second) + ...: deterministic, not bit-identical to the
+//     one-chain sum of an uncut tile.
 //   flags: 0x200 fused GEGLU (as mc_gemm_f16); 0x1 = do not assume that stores and loads retire in issue order (A/B);
-//     bits 16-23: cap on the number of workgroups / 8 (0 = one per CU) - tests.
-// MC_ERR_UNSUPPORTED: shapes outside the kernel (N % 8, K < 256, fewer than 8 row tiles, operands >= 2 GiB) - call mc_gemm_f16.
-extern "C" long mc_workspace_bytes_gemm_tileloop(void) { return 64; }
+//     0x2 = stream-K; bits 16-23: cap on the number of workgroups / 8 (0 = one per CU) - tests.
+// MC_ERR_UNSUPPORTED: shapes outside the kernel (N % 8, K < 256, fewer than 8 row tiles without stream-K, two-source A,
+// per-batch bias, operands >= 2 GiB) - call mc_gemm_f16.
+extern "C" long mc_workspace_bytes_gemm_tileloop(int which) {
+    return which == 0 ? (long)gemm6_counter_bytes() : which == 1 ? (long)gemm6_slab_bytes() : -1;
+}
 
 extern "C" int mc_gemm_tileloop_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
                                     int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int rows_per_batch,
-                                    float alpha, int flags, void* workspace, size_t ws_bytes, void* stream) {
+                                    float alpha, int flags, void* workspace, size_t ws_bytes, void* partials,
+                                    size_t partial_bytes, void* stream) {
     if (M <= 0 || N <= 0 || K <= 0 || !A || !W || !C) return MC_ERR_SHAPE;
     const int epi = (flags & 0x200) ? 1 : 0;
     if (epi && (R || N % 16)) return MC_ERR_UNSUPPORTED;
     if (K % BK || N % 4 || ldc % 4 || (R && (ldr % 4))) return MC_ERR_SHAPE;
     if (lda % 8 || (A2 && lda2 % 8)) return MC_ERR_SHAPE;
     if (c1 <= 0 || c1 > K || c1 % BK || (c1 < K && !A2)) return MC_ERR_SHAPE;
-    if (workspace && (ws_bytes < 64 || ((uintptr_t)workspace & 3))) return MC_ERR_SHAPE;
+    if (workspace && (ws_bytes < gemm6_counter_bytes() || ((uintptr_t)workspace & 3))) return MC_ERR_SHAPE;
+    const bool sk = (flags & 0x2) != 0;
+    if (sk && (!workspace || !partials || partial_bytes < gemm6_slab_bytes() || ((uintptr_t)partials & 15))) return MC_ERR_SHAPE;
     if (rows_per_batch <= 0) rows_per_batch = M;
     GemmParams p;
     p.A = (const half_t*)A; p.A2 = (const half_t*)A2; p.W = (const half_t*)W;
@@ -273,9 +288,9 @@ extern "C" int mc_gemm_tileloop_f16(const void* A, const void* A2, const void* W
     p.c1 = c1; p.ctot = K; p.Hs = p.Ws = p.Ho = p.Wo = 0;
     p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi; p.s2_pad = 1;
     p.ws = nullptr; p.splits = 1; p.dbg = 0;
-    if (bias && rows_per_batch < M && (size_t)M * ldc * 2 > (size_t)0x7FFFFFF0u) return MC_ERR_UNSUPPORTED;
-    g_last_kernel = 61;
-    return gemm6_dispatch(p, flags & 1, (uint32_t*)workspace, ((flags >> 16) & 0xFF) * 8, (hipStream_t)stream);
+    g_last_kernel = sk ? 62 : 61;
+    return gemm6_dispatch(p, flags & 1, sk ? 2 : (workspace ? 1 : 0), (uint32_t*)workspace, (float*)partials,
+                          ((flags >> 16) & 0xFF) * 8, (hipStream_t)stream);
 }
 
 // ---- norm + GEMM in one launch (round 4) ------------------------------------------------------------------------------

@@ -218,6 +218,8 @@ class UNet3DEngine:
                 raise NotImplementedError("motion_guidance_blocks entry %r cannot be honoured (last entry: %r)"
                                           % (blk, self.guidance_blocks[-1]))
         self.grad_scale = float(grad_scale)
+        if self.dev.type == "cuda":
+            ops.prepare_tile_counters(self.dev)   # the tile loop's zeroed counter slab must exist before any graph capture
         # guided / plain steps feed the UNet a batch whose halves differ in the text only: run what precedes the first
         # cross-attention once (forward: dup).  False = the duplicated batch of rounds 1-4 (A/B: bench.py --no-shared-prefix)
         self.share_prefix = True

@@ -26,8 +26,8 @@ SIGNATURES = {
     "mc_workspace_bytes_attn_bwd": [I, I, I],
     "mc_workspace_bytes_tattn_loss": [I, I, I],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
-    "mc_workspace_bytes_gemm_tileloop": [],
-    "mc_gemm_tileloop_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P, ctypes.c_size_t, P],
+    "mc_workspace_bytes_gemm_tileloop": [I],
+    "mc_gemm_tileloop_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P, ctypes.c_size_t, P, ctypes.c_size_t, P],
     "mc_norm_gemm_f16": [P, P, P, P, I, I, I, I, I, I, P, P, P, I, I, F, P, P, I, P],
     "mc_gemm_splitk_plan": [I, I, I, I],
     "mc_gemm_last_kernel": [],

@@ -115,11 +115,12 @@ def gemm_share():
 
 
 # ---- persistent tile loop (mc_gemm_tileloop_f16) ------------------------------------------------------------------------
-# Counter blocks of the dynamic tile order: 64 zero bytes per (owner, stream).  The kernel zeroes its block before it ends, and
+# Counter blocks of the dynamic tile order / stream-K flags: 2 KiB of zero bytes per (owner, stream).  The kernel zeroes its block before it ends, and
 # the launches of one owner on one stream (or inside the graphs captured from it) run one after the other, so ONE block per
 # key is enough; keys never share a block, so launch sequences that overlap (lanes) never meet in a counter.  Blocks are cut
 # from a slab that is allocated and zeroed OUTSIDE any graph capture (handing out a block is pointer arithmetic).
-_TILE_SLAB_BLOCKS = 4096
+_TILE_SLAB_BLOCKS = 512
+_TILE_BLOCK_BYTES = 2048
 _tile_slabs = {}     # device -> zeroed int32 tensor
 _tile_blocks = {}    # (id(owner), device, stream) -> byte address
 _tile_lock = threading.Lock()
@@ -131,7 +132,7 @@ def prepare_tile_counters(device):
     key = str(device)
     with _tile_lock:
         if key not in _tile_slabs:
-            _tile_slabs[key] = torch.zeros(_TILE_SLAB_BLOCKS * 16, dtype=torch.int32, device=device)
+            _tile_slabs[key] = torch.zeros(_TILE_SLAB_BLOCKS * _TILE_BLOCK_BYTES // 4, dtype=torch.int32, device=device)
     return _tile_slabs[key]
 
 
@@ -151,20 +152,23 @@ def _tile_counter_block(t, stream):
             n = sum(1 for k in _tile_blocks if k[1] == dkey)
             if n >= _TILE_SLAB_BLOCKS:
                 return None
-            addr = _tile_blocks[key] = slab.data_ptr() + 64 * n
+            addr = _tile_blocks[key] = slab.data_ptr() + _TILE_BLOCK_BYTES * n
     return addr
 
 
 def _tileloop_wanted(M, N, K, share):
-    """measured policy (profiles/r06_tileloop.md): the wide-N short-K Linear layers and whatever has several rounds of tiles"""
-    if M < 2048 or N % 320 or K < 256:
+    """measured policy (profiles/r06_tileloop.md): every DENSE problem that mc_gemm_f16 would run on gemm5's 256x320 tiles - the
+    persistent loop is 4 ... 20 % faster on all of them (the K = 320 layers of the 64x64 level stay on the streaming kernel)"""
+    if N % 320 or K < 256 or K % 64:
         return False
-    tiles = ((M + 255) // 256) * (N // 320)
-    return N >= 3840 and K <= 2560 and tiles >= 256
+    if K == 320 and (M >= 98304 or (M >= 32768 and N >= 640)):
+        return False
+    rows = (M + 255) // 256
+    return rows >= 8 and rows * (N // 320) >= (224 >> share)
 
 
 def gemm_tileloop(a, w, *, a2=None, bias=None, residual=None, out=None, alpha=1.0, rows_per_batch=0, geglu=False,
-                  dynamic=True, strict_order=False, max_wg=0):
+                  dynamic=True, strict_order=False, max_wg=0, stream_k=False):
     """`gemm` (DENSE) on the persistent tile loop: out = alpha * [a | a2] . w^T + bias + residual, bit-identical to the
     256x320 kernel of mc_gemm_f16.  Returns None when the shape is outside the kernel (caller: `gemm`)."""
     _f16(a), _f16(w)
@@ -179,10 +183,16 @@ def gemm_tileloop(a, w, *, a2=None, bias=None, residual=None, out=None, alpha=1.
         _f32(bias)
         assert bias.shape[-1] == N
     st = _stream(a)
-    ctr = _tile_counter_block(a, st) if dynamic else None
-    flags = (0x200 if geglu else 0) | (1 if strict_order else 0) | ((max_wg // 8) << 16)
+    ctr = _tile_counter_block(a, st) if (dynamic or stream_k) else None
+    part = None
+    if stream_k:
+        if ctr is None:
+            return None
+        part = torch.empty(lib.workspace_bytes("gemm_tileloop", 1) // 4, dtype=torch.float32, device=a.device)
+    flags = (0x200 if geglu else 0) | (1 if strict_order else 0) | (2 if stream_k else 0) | ((max_wg // 8) << 16)
     ok = lib.try_call("mc_gemm_tileloop_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
-                      _ld(a2), _ld(out), _ld(residual), c1, rows_per_batch, float(alpha), flags, ctr, 64 if ctr else 0, st)
+                      _ld(a2), _ld(out), _ld(residual), c1, rows_per_batch, float(alpha), flags, ctr,
+                      _TILE_BLOCK_BYTES if ctr else 0, _p(part), part.numel() * 4 if part is not None else 0, st)
     return out if ok else None
 
 

@@ -43,6 +43,15 @@ def _cost(name, a):
         nout = N // 2 if geglu else N
         nbytes = 2.0 * (rows_in * k_in + N * K + M * nout * (2 if a[4] else 1))
         return ("gemm", 2.0 * M * N * K, nbytes, (mode, M, N, K, geglu, bool(a[4])))
+    if name == "mc_gemm_tileloop_f16":
+        # (A, A2, W, C, R, bias, M, N, K, lda, lda2, ldc, ldr, c1, rows_per_batch, alpha, flags, workspace, ws_bytes, partials,
+        #  partial_bytes, stream)
+        M, N, K, flags = a[6], a[7], a[8], a[16]
+        geglu = bool(flags & 0x200)
+        nout = N // 2 if geglu else N
+        nbytes = 2.0 * (M * K + N * K + M * nout * (2 if a[4] else 1))
+        return ("gemm6<256x320 tile loop%s> DENSE" % (", stream-K" if flags & 2 else ""), 2.0 * M * N * K, nbytes,
+                (0, M, N, K, geglu, bool(a[4])))
     if name == "mc_norm_gemm_f16":
         # (A, W, C, bias, M, N, K, lda, ldc, kind, gamma, beta, pe, hw, nframes_pe, eps, stats, partial, flags, stream)
         M, N, K, kind, flags = a[4], a[5], a[6], a[9], a[18]

@@ -154,6 +154,35 @@ def test_gemm6_persistent_tile_loop_equals_gemm5_bit_for_bit(backend, dynamic):
     assert ops.gemm_tileloop(a, w) is None                      # K < 256
 
 
+def test_gemm6_stream_k_cuts_tiles_along_k(backend):
+    """mc_gemm_tileloop_f16 flags 0x2: the k-stages of every XCD's tile list are dealt evenly to the workgroups; a tile that a range
+    boundary falls into is cut along k, the later pieces' fp32 sums reach the owner of the first piece through the slabs + flags
+    (device-scope hand-over), summed in k order.  Against gemm5 (one chain per element): equal where no tile is cut, within one
+    fp16 rounding of the fp32 result elsewhere; fewer than 8 rows of tiles (flat tile lists); flags are zero again afterwards."""
+    dev = backend
+    shapes = [(2304, 960, 1024, 16), (1024, 1280, 1280, 0), (512, 640, 2048, 0)] if not big(dev) else \
+             [(8192, 3840, 1280, 0), (2048, 3840, 1280, 0), (4096, 1280, 5120, 0), (1024, 1280, 1280, 0)]
+    for (M, N, K, cap) in shapes:
+        a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+        bias = torch.randn(1, N, generator=torch.Generator().manual_seed(3)).to(dev)
+        res = rnd((M, N), dev, 4)
+        for (b, r) in [(None, None), (bias, res)]:
+            out = torch.full((M, N), float("nan"), dtype=torch.float16, device=dev)
+            assert ops.gemm_tileloop(a, w, bias=b, residual=r, alpha=0.5, out=out, stream_k=True, max_wg=cap) is not None
+            lin = 0.5 * (a.float() @ w.float().t()) + (b if b is not None else 0)
+            close(out, lin.half().float() + (r.float() if r is not None else 0), 2e-2, 5e-3, "stream-K %d %d %d" % (M, N, K))
+            again = torch.empty_like(out)
+            ops.gemm_tileloop(a, w, bias=b, residual=r, alpha=0.5, out=again, stream_k=True, max_wg=cap)
+            assert torch.equal(out, again), "stream-K is not reproducible"
+        wg = ops.interleave_geglu(rnd((N, K), dev, 8, 0.1))
+        bg = ops.interleave_geglu(torch.randn(N, generator=torch.Generator().manual_seed(9))).unsqueeze(0).to(dev)
+        y = a.float() @ wg.float().t() + bg
+        out = ops.gemm_tileloop(a, wg, bias=bg, geglu=True, stream_k=True, max_wg=cap)
+        close(out, y[:, 0::2] * Fn.gelu(y[:, 1::2]), 2e-2, 1e-2, "stream-K geglu")
+    for slab in ops._tile_slabs.values():
+        assert int(slab.count_nonzero()) == 0, "a launch left its hand-over flags dirty"
+
+
 @pytest.mark.parametrize("mode", ["s2", "up", "tconv"])
 def test_gemm5_conv_modes(backend, mode):
     dev = backend

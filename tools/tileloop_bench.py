@@ -38,6 +38,14 @@ SHAPES = [
     ("ff2_l0 +R", 131072, 320, 1280, True, True, False),
     ("ff1_l2 B=1 geglu", 4096, 10240, 1280, True, False, True),
     ("qkv_l2 B=1", 4096, 3840, 1280, False, False, False),
+    # the 8x8 level (and the backward of the 16x16 one): few tiles - what split-K + reduce / the small tiles serve today
+    ("small qkv_l3", 2048, 3840, 1280, False, False, False),
+    ("small proj_l3 +R", 2048, 1280, 1280, True, True, False),
+    ("small ff1_l3 geglu", 2048, 10240, 1280, True, False, True),
+    ("small ff2_l3 +R", 2048, 1280, 5120, True, True, False),
+    ("small ff2_l2 bwd", 4096, 5120, 1280, False, False, False),
+    ("small proj_l2 bwd", 4096, 1280, 1280, False, False, False),
+    ("small ff1_l2 bwd (K=5120)", 4096, 1280, 5120, False, False, False),
 ]
 
 
@@ -86,6 +94,17 @@ def main():
                         break
                     bad += int((got != ref).sum().item()) + int(torch.isnan(got).sum().item())
                 ident["%s %s%s" % (label, "dynamic" if dyn else "static", " strict" if strict else "")] = bad
+            # stream-K: cut tiles are summed piecewise - compared with a tolerance (one fp16 ulp of the largest element)
+            worst = 0.0
+            for _ in range(a.reps):
+                got.fill_(float("nan"))
+                r = ops.gemm_tileloop(x, w, out=got, stream_k=True, **kws)
+                if r is None:
+                    worst = -1.0
+                    break
+                d = (got.float() - ref.float()).abs().max().item()
+                worst = float("nan") if d != d else max(worst, d)
+            ident["%s stream-K max|diff| (ref max %.3g)" % (label, ref.float().abs().max().item())] = worst
             del ref, got
         torch.cuda.synchronize()
         dirty = sum(int(v.count_nonzero().item()) for v in ops._tile_slabs.values())
@@ -99,9 +118,17 @@ def main():
             ("tile loop static", lambda: ops.gemm_tileloop(x, w, out=o_t, dynamic=False, **kw)),
             ("tile loop dynamic", lambda: ops.gemm_tileloop(x, w, out=o_t, dynamic=True, **kw)),
             ("tile loop dynamic, stores drained", lambda: ops.gemm_tileloop(x, w, out=o_t, dynamic=True, strict_order=True, **kw)),
+            ("tile loop stream-K", lambda: ops.gemm_tileloop(x, w, out=o_t, stream_k=True, **kw)),
             ("library's own choice (ops.gemm)", lambda: ops.gemm(x, w, out=o_t, **kw)),
+            # the bare product (what the vendor arm computes): tools/vendor_anchor.py's comparison
+            ("gemm5 plain", lambda: ops.gemm(x, w, cfg=11, out=o_v)),
+            ("tile loop dynamic plain", lambda: ops.gemm_tileloop(x, w, out=o_v, dynamic=True)),
+            ("tile loop stream-K plain", lambda: ops.gemm_tileloop(x, w, out=o_v, stream_k=True)),
         ]
         for arm, fn in arms:
+            if fn() is None:
+                print(json.dumps(dict(shape=name, arm=arm, refused=True)), flush=True)
+                continue
             us, t0, t1, n = run_window(fn, a.window, iters)
             watts, mhz, ns = smi.window(t0, t1)
             row = dict(shape=name, M=M, N=N, K=K, arm=arm, us=round(us, 2), TFLOPs=round(flop / us / 1e6, 1), calls=n,
