@@ -235,6 +235,15 @@ def family_of_traced_kernel(name):
     return None
 
 
+def loaded_lib_stamp():
+    """Source stamp of the HIP library this process loaded (written by motionclone_amd/build.py next to the .so); None if absent."""
+    from motionclone_amd import lib
+    try:
+        return open(lib.HIP_LIB_PATH + ".stamp").read().strip()
+    except OSError:
+        return None
+
+
 def timed_roofline(roof_all, prof):
     """The dominant GEMM family IN THE TIMED REGIME (hipGraph replay, several videos in flight): HIP events cannot bracket
     launches inside a graph replay, so the per-launch DURATION comes from a rocprofv3 --kernel-trace --stats run of this same
@@ -245,6 +254,13 @@ def timed_roofline(roof_all, prof):
     family's launches sustain per unit of GPU time they occupy."""
     if not prof or not roof_all:
         return None
+    # a trace is only this run's kernels if it was taken from THIS library on THIS device: tools/kernel_stats_md.py records the
+    # library's source stamp (build.py's sha1 of sources + flags, next to the .so) and the device name; anything else is refused
+    stamp, devname = loaded_lib_stamp(), torch.cuda.get_device_name(0)
+    if prof.get("lib_stamp") is None or prof.get("lib_stamp") != stamp or prof.get("device") != devname:
+        return dict(achieved=None, frac=None, source=TIMED_DURATIONS_FILE, code=prof.get("code"),
+                    reason="stale trace: recorded for library stamp %s on %s, this run loaded %s on %s - re-run the profile (tools/gpu_profile.sh)"
+                           % (str(prof.get("lib_stamp"))[:12], prof.get("device"), str(stamp)[:12], devname))
     groups = {}
     for name, k in prof.get("kernels", {}).items():
         fam = family_of_traced_kernel(name)
@@ -290,17 +306,18 @@ def compact_line(res, detail_path, limit=4000):
     long.  Everything else (`roofline_by_kernel`, traffic per shape, VAE, eager loop, baselines) goes to `detail_path`."""
     keep = ["metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "sec_per_guided_step", "sec_per_plain_step", "sec_per_denoise_step",
-            "e2e_tflops_per_gpu", "e2e_frac_of_mfma_peak", "videos_per_min_incl_vae"]
+            "sec_per_denoise_step_throughput", "e2e_tflops_per_gpu", "e2e_frac_of_mfma_peak", "videos_per_min_incl_vae"]
     line = {k: res[k] for k in keep if k in res}
     r = res.get("roofline")
     if r:
         line["roofline"] = {k: r.get(k) for k in ("kernel", "bound", "achieved", "peak", "unit", "frac", "traffic",
-                                                  "traffic_vs_algorithmic", "avg_launch_us", "launches",
+                                                  "traffic_vs_algorithmic", "traffic_launch_coverage", "avg_launch_us", "launches",
                                                   "share_of_probe_video", "regime")}
     rt = res.get("roofline_timed")
     if rt:
         line["roofline_timed"] = {k: rt.get(k) for k in ("kernel", "achieved", "frac", "avg_launch_us", "overlap",
-                                                         "share_of_kernel_time", "source")}
+                                                         "share_of_kernel_time", "source", "code", "reason")
+                                  if rt.get(k) is not None or k in ("achieved", "frac")}
     c = res.get("cpu_baseline")
     if c:
         line["cpu_baseline"] = {k: c.get(k) for k in ("value", "unit", "cores", "cpu_model", "kind", "sample", "error")
@@ -421,7 +438,10 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+        # rank 0 alone runs the eager / probe videos and the baselines after the timed region while the others wait in the final
+        # barrier: a timeout well past that post-work, so RCCL's watchdog never tears the job down before the line is printed
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(hours=2))
     lib.load()  # fails loudly if the gfx950 library is missing
     if args.no_norm_fusion:
         ops.NORM_GEMM_MIN_ROWS = 1 << 62
@@ -447,6 +467,7 @@ def main():
     if args.sparsectrl:
         from motionclone_amd.engine import ControlNetEngine
         ceng = ControlNetEngine(spec.synthetic_controlnet_state_dict(cfg, seed=4321, device=dev), cfg, dev)
+        ceng.share_prefix = eng.share_prefix     # --no-shared-prefix is an A/B of BOTH networks
     smp = MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                              num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE, controlnet=ceng,
                              batch_guided=not args.two_b1_guided)

@@ -56,21 +56,30 @@ def _deps():
 TOOLS_LIB = os.path.join(REPO, "tools", "_build", "libmotionclone_hip_tools.so")
 
 
-def build_hip(force=False, verbose=False, tools=False):
+OLD_EPI_LIB = os.path.join(REPO, "tools", "_build", "libmotionclone_hip_oldepi.so")
+
+
+def build_old_epilogue_control(force=False):
+    """A/B ONLY (bench.py through MC_HIP_LIB): the product sources with gemm5's one-pass kernels on round 5's epilogue
+    (-DMC_G5_OLD_EPILOGUE) - what the round-6 epilogue of the convolutions is measured against."""
+    return build_hip(force=force, out_lib=OLD_EPI_LIB, extra=["-DMC_G5_OLD_EPILOGUE"], objdir=os.path.join(REPO, "tools", "_build", "obj_oldepi"))
+
+
+def build_hip(force=False, verbose=False, tools=False, out_lib=None, extra=(), objdir=None):
     """Compile every HIP source for gfx950 and link csrc/libmotionclone_hip.so.
 
     tools=True: the same sources with -DMC_TOOLS -> tools/_build/libmotionclone_hip_tools.so, the library the A/B scripts
     under tools/ load through MC_HIP_LIB: it reads the MC_* environment switches and exports mc_gemm_debug* /
     mc_tattn_debug_buffer.  The product library (tools=False) has no environment read and no mutable global."""
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    flags = HIP_FLAGS + (["-DMC_TOOLS"] if tools else [])
-    out_lib = TOOLS_LIB if tools else HIP_LIB
+    flags = HIP_FLAGS + (["-DMC_TOOLS"] if tools else []) + list(extra)
+    out_lib = out_lib or (TOOLS_LIB if tools else HIP_LIB)
     stamp = _stamp(_deps(), " ".join(flags) + repr(sorted(FILE_FLAGS.items())))
     stamp_file = out_lib + ".stamp"
     if not force and os.path.exists(out_lib) and os.path.exists(stamp_file):
         if open(stamp_file).read() == stamp:
             return out_lib
-    objdir = os.path.join(os.path.dirname(TOOLS_LIB), "obj") if tools else os.path.join(CSRC, "build")
+    objdir = objdir or (os.path.join(os.path.dirname(TOOLS_LIB), "obj") if tools else os.path.join(CSRC, "build"))
     os.makedirs(objdir, exist_ok=True)
 
     def one(src):

@@ -28,12 +28,12 @@ namespace mc {
 // VAR (timing experiments, tools/gemm5_bench.py): bit 0 = STAGGER the LDS-DMA issue between the two waves of a SIMD (waves 0-3
 // in the first half of a stage, waves 4-7 in the second; measured 1-8 % slower than everybody in the first half, which is the
 // default), bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
-template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS>
-__global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
+template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS, int RES = 0>
+__global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
                                                                           uint32_t bytesW, int tilesM, int tilesN, int sm, int sn) {
     using g5::TN; using g5::BKT; using g5::RPI; using g5::STG; using g5::lds_off32;
     using T = g5::Tile<BM, BN, NW, NS>;
-    constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB, WB = T::WB, WX = T::WX;
+    constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB, WB = T::WB, WX = T::WX, WXD = T::WXD;
     constexpr int WMW = T::WMW;
     MC_DYN_SMEM(smem);
 
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmPar
     uint32_t w_off[WB + 1];
 #pragma unroll
     for (int i = 0; i <= WB; ++i) {
-        int n = n0 + (i < WB ? wave + NW * i : WB * NW + (wave % WX)) * RPI + rsub;
+        int n = n0 + (i < WB ? wave + NW * i : WB * NW + (wave % WXD)) * RPI + rsub;
         w_off[i] = n < p.N ? (uint32_t)n * (uint32_t)p.K * 2u + (uint32_t)lslot * 16u : kOOB;
     }
 
@@ -156,7 +156,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmPar
         } else {
             const int i = piece - RA;
             uint32_t voff = w_off[i] + (uint32_t)kt * (BKT * 2u);   // kOOB + a small offset stays out of range
-            glds16(bufW, voff, base + A_BYTES + (i < WB ? wave + NW * i : WB * NW + (wave % WX)) * 1024);
+            glds16(bufW, voff, base + A_BYTES + (i < WB ? wave + NW * i : WB * NW + (wave % WXD)) * 1024);
         }
     };
     auto issue_stage = [&](int kt, int buf) {
@@ -234,7 +234,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmPar
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
 #pragma unroll
-            for (int j = 0; j < TM; ++j) acc[i][j] = mfma32(cw[i], ca[j], acc[i][j]);
+            for (int j = 0; j < TM; ++j) {
+                if constexpr (TM == 4) {         // one wave per SIMD, 320 accumulators: column blocks 0-3 in AGPRs, 4 in VGPRs
+                    if (i < 4) mfma32_agpr(acc[i][j], cw[i], ca[j]); else mfma32_vgpr(acc[i][j], cw[i], ca[j]);
+                } else {
+                    acc[i][j] = mfma32(cw[i], ca[j], acc[i][j]);
+                }
+            }
             rw[i] = *reinterpret_cast<const half8_t*>(bW + lds_off32(wn0 + 32 * i + l31, 2 * rks + lhi));
             if (i < NL) issue_piece(lkt, lbuf, P0 + i);
         }
@@ -307,6 +313,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmPar
             buf = nbuf;
         }
     }
+    // Round 6: the one-pass kernels leave through gemm6's epilogue (tile_epilogue: straight-line buffer loads / stores, bias through
+    // an LDS strip, residual rows of pass p + 1 requested in front of the stores of pass p) whenever the tile's bias is ONE row -
+    // no bias, a single row, or per-batch rows with rows_per_batch a multiple of the tile height.  The old epilogue waited
+    // with vmcnt(0) for every predicated bias / residual load, i.e. for all stores issued before it: 9 us per 256x320 tile
+    // with bias + residual (tools/tileloop_bench.py: attn_out_l1 46.0 us as used vs 33.3 plain; the new one 39.1 vs 35.4).
+    // The wave's 160 bias values are requested here, in front of the last ring stages (the counted waits below only get stricter).
+    const bool new_epi = !p.ws;      // (gemm5_dispatch admits only problems whose tiles see ONE bias row)
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (new_epi && p.bias) bias4 = load_bias4(p.bias, p.rows_per_batch >= p.M ? 0 : m0 / p.rows_per_batch, p.N, n0 + wn0);
     // tail: nothing left to issue (the next stage's slice-0 fragments read after the last stage are stale and never used)
     for (; kt < nk; ++kt) {
         const int nbuf = nxt(buf);
@@ -336,7 +351,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 1 : 2) void gemm5_kernel(GemmPar
                 }
         return;
     }
+#ifdef MC_G5_OLD_EPILOGUE   // A/B build only (build.build_old_epilogue_control): round 5's epilogue
     g5_epilogue<EPI, TM>(p, acc, smem + wave * STG, m0 + wm0, n0 + wn0, lane);
+    return;
+#endif
+    if (new_epi) {
+        EpiArgs e;
+        e.C = p.C; e.R = p.R; e.M = p.M; e.N = p.N; e.ldc = p.ldc; e.ldr = p.ldr; e.alpha = p.alpha;
+        const size_t outc = EPI == 1 ? (size_t)p.N / 2 : (size_t)p.N;
+        e.bytesC = (uint32_t)(((size_t)(p.M - 1) * p.ldc + outc) * 2);
+        e.bytesR = p.R ? (uint32_t)(((size_t)(p.M - 1) * p.ldr + outc) * 2) : 0u;
+        e.has_bias = p.bias != nullptr;
+        char* img = smem + wave * (32 * g5::RSG);                       // 32 rows x 80 columns per wave
+        char* bstrip = smem + NW * (32 * g5::RSG) + wave * 640;         // 160 fp32 per wave
+        tile_epilogue<EPI, RES, TM>(e, acc, img, bstrip, bias4, m0 + wm0, n0 + wn0);   // RES: with a residual (its own instantiation:
+        return;                                                                          // as a run-time branch the pair spilled)
+    }
 }
 
 // Split-K second pass: one wave per wave tile.  Sums the `splits` slabs of its wave tile in split order (deterministic),
@@ -377,11 +407,11 @@ __global__ __launch_bounds__(64) void splitk_reduce5_kernel(GemmParams p, int ti
     g5_epilogue<0, TM>(p, acc, smem, tm * (128 * TM) + wr * (32 * TM), tn * BN + wc * 160, lane);
 }
 
-template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS>
-static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
+template <int MODE, int EPI, int VAR, int BM, int BN, int NW, int NS, int RES>
+static int launch5r(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
     using T = g5::Tile<BM, BN, NW, NS>;
     int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
-    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS>, T::SMEM);
+    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS, RES>, T::SMEM);
     // super-tile of the XCD-local tile order: sn divides the N-tiles, sm x sn ~ the workgroups an XCD holds at a time (32 CUs x
     // 1 or 2), least operand rows per tile
     const int rows_per_xcd = (tM + 7) / 8;
@@ -402,7 +432,7 @@ static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, 
     }
     const int groups = (rows_per_xcd + sm - 1) / sm;
     dim3 grid((unsigned)(groups * sm * 8 * tN), (unsigned)p.splits);
-    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS>), grid, dim3(T::NTH), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
+    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS, RES>), grid, dim3(T::NTH), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
     if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
     if constexpr (NW == 8 && BN == g5::BN) {   // (the split-K slabs / reduce pass are laid out for the 8-wave geometries)
         if (p.ws) {
@@ -413,8 +443,18 @@ static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, 
     return MC_OK;
 }
 
-// var: 0 = shipped schedule, 256-row tiles; 1 / 2 / 3 = schedule experiments (dense and stride-1 conv); 4 = 128-row tiles;
-// 5 = 256 x 160 tiles, 4 waves, ring of three: two workgroups per CU (dense only, no split-K)
+template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS>
+static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
+    if constexpr (EPI == 0) {
+        if (p.R && !p.ws) return launch5r<MODE, EPI, VAR, BM, BN, NW, NS, 1>(p, bA, bA2, bW, stream);
+    }
+    return launch5r<MODE, EPI, VAR, BM, BN, NW, NS, 0>(p, bA, bA2, bW, stream);
+}
+
+// var: 0 = 256-row tiles, 8 waves; 4 = 128-row tiles; 5 = 256 x 160 tiles, 4 waves, ring of three: two workgroups per CU (dense
+// only, no split-K); 6 = 256 x 320 tiles, FOUR waves with 128 x 160 wave tiles (one wave per SIMD, round 6; no split-K).
+// (1 / 2 / 3 were round 4's schedule experiments - staggered / burst LDS-DMA issue, measured 1 - 8 % slower: the VAR template
+// parameter still builds them, nothing instantiates them any more.)
 template <int MODE>
 static int launch5_var(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, int var, hipStream_t s) {
     if (var == 5) {
@@ -425,17 +465,20 @@ static int launch5_var(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t 
         }
         return MC_ERR_UNSUPPORTED;
     }
+    if (var == 6) {
+        if (p.ws) return MC_ERR_UNSUPPORTED;
+        if (p.epi == 1) {
+            if constexpr (MODE == DENSE) return launch5<DENSE, 1, 0, 256, 320, 4, 4>(p, bA, bA2, bW, s);
+            return MC_ERR_UNSUPPORTED;
+        }
+        return launch5<MODE, 0, 0, 256, 320, 4, 4>(p, bA, bA2, bW, s);
+    }
     if (p.epi == 1) {
         if (MODE != DENSE) return MC_ERR_UNSUPPORTED;
         return var == 4 ? launch5<DENSE, 1, 0, 128>(p, bA, bA2, bW, s) : launch5<DENSE, 1, 0, 256>(p, bA, bA2, bW, s);
     }
     if (var == 0) return launch5<MODE, 0, 0, 256>(p, bA, bA2, bW, s);
     if (var == 4) return launch5<MODE, 0, 0, 128>(p, bA, bA2, bW, s);
-    if constexpr (MODE == DENSE || MODE == CONV_S1) {   // schedule experiments (tools/gemm5_bench.py)
-        if (var == 1) return launch5<MODE, 0, 1, 256>(p, bA, bA2, bW, s);
-        if (var == 2) return launch5<MODE, 0, 2, 256>(p, bA, bA2, bW, s);
-        if (var == 3) return launch5<MODE, 0, 3, 256>(p, bA, bA2, bW, s);
-    }
     return MC_ERR_UNSUPPORTED;
 }
 
@@ -449,8 +492,15 @@ int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStre
     if ((p.ws != nullptr) != (p.splits > 1)) return MC_ERR_UNSUPPORTED;
     if (p.ws && (p.epi == 1 || (var != 0 && var != 4))) return MC_ERR_UNSUPPORTED;
     if (var == 5 && mode != DENSE) return MC_ERR_UNSUPPORTED;
+    if (var == 1 || var == 2 || var == 3 || var > 6) return MC_ERR_UNSUPPORTED;
     if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
     if (p.epi == 1 && (p.N & 15)) return MC_ERR_UNSUPPORTED;
+    if (!p.ws) {
+        // the one-pass epilogue (tile_epilogue) reads ONE bias row per tile and addresses C / R through 2 GiB descriptors
+        const int bm = var == 4 ? 128 : 256;
+        if (p.bias && p.rows_per_batch < p.M && p.rows_per_batch % bm) return MC_ERR_UNSUPPORTED;
+        if ((size_t)p.M * p.ldc * 2 > lim || (p.R && (size_t)p.M * p.ldr * 2 > lim)) return MC_ERR_UNSUPPORTED;
+    }
     switch (mode) {
         case DENSE: return launch5_var<DENSE>(p, bytesA, bytesA2, bytesW, var, stream);
         case CONV_S1: return launch5_var<CONV_S1>(p, bytesA, bytesA2, bytesW, var, stream);

@@ -17,6 +17,9 @@ constexpr int STG = 32 * RS;             // one 32-row block of a wave's tile
 // Geometries (wave tile = 32 TM rows x 160 columns of v_mfma_f32_32x32x16_f16, TN = 5 column blocks):
 //   <256, 320, 8, 4>  8 waves as 4 x 2, wave tile 64 x 160, ring of 4 stages (144 KiB): ONE workgroup per CU - the default
 //   <128, 320, 8, 4>  8 waves, wave tile 32 x 160: problems that do not fill the 256 CUs with 256-row tiles (16x16 / 8x8 levels)
+//   <256, 320, 4, 4>  (round 6) 4 waves as 2 x 2, ONE wave per SIMD with the whole 512-register file: wave tile 128 x 160 -
+//                     36 % fewer LDS fragment bytes per MFMA than the 64 x 160 wave tile (461 instead of 717), half the waves
+//                     at every barrier; 320 accumulator registers per lane
 //   <256, 160, 4, 3>  (round 4) 4 waves as 4 x 1, wave tile 64 x 160, ring of 3 stages (78 KiB): TWO workgroups per CU that
 //                     run out of step - one tile's prologue / epilogue (residual read, stores) under the other's k-loop.  Same
 //                     per-wave code as the default (TM = 2), 1.44x the operand bytes per MFMA (A is fetched once per 160
@@ -34,7 +37,8 @@ struct Tile {
     static constexpr int LB = RA + WB, LA = RA + WB + 1; // LDS-DMA instructions per stage: waves >= WX / waves < WX
     static constexpr size_t SMEM = (size_t)NS_ * STAGE;
     static_assert(BN_ % 160 == 0 && NW_ % WNW == 0 && BM % (32 * WMW) == 0 && BM % (RPI * NW_) == 0, "tile / wave grid");
-    static_assert(WX > 0 && NW_ * STG <= NS_ * STAGE, "epilogue image must fit the ring");
+    static constexpr int WXD = WX > 0 ? WX : 1;          // (divisor of `wave % WX` where no wave moves an extra group)
+    static_assert(NW_ * (32 * RSG + 640) <= NS_ * STAGE, "epilogue images must fit the ring");
     static_assert(NS_ == 3 || NS_ == 4, "ring depth");
 };
 
@@ -112,6 +116,160 @@ __device__ __forceinline__ void g5_epilogue(const GemmParams& p, f32x16 (&acc)[g
             }
         }
         wave_lds_sync();   // the image is rewritten by the next half
+    }
+}
+
+
+// ---- the round-6 epilogue (gemm6.hip; gemm5.hip's one-pass kernels use it too) -------------------------------------------------
+#ifdef MC_EMU
+#define MC_SCHED_FENCE() ((void)0)
+#else
+#define MC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#endif
+
+// The lane index, recomputed where it is needed (two VALU instructions) instead of kept: nothing inside the k-loop reads it,
+// so a lane index (or anything derived from it) that lives across the loop is spilled to scratch, and every reload is a
+// scratch_load + s_waitcnt vmcnt(0) - a drain of the operand ring and of the epilogue's stores.  `opaque` keeps hipcc from
+// hoisting the recomputation (and every address that depends on it) back out of the tile loop.
+#ifdef MC_EMU
+__device__ inline int lane_now() { return (int)(threadIdx.x & 63); }
+#else
+__device__ __forceinline__ int lane_now() {
+    return opaque((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
+}
+#endif
+
+// what the epilogue reads (by value: the callers fetch it where they need it)
+struct EpiArgs {
+    half_t* C;
+    const half_t* R;
+    int M, N, ldc, ldr;
+    float alpha;
+    uint32_t bytesC, bytesR;
+    bool has_bias;
+};
+
+// the wave's 160 bias values of output columns [n0, n0 + 160) of bias row `row` (row-major [rows][N] fp32): lane l < 40 gets
+// columns 4 l .. 4 l + 3 (out of range: zeros) - ONE load, issued a k-stage or more ahead of the epilogue
+__device__ __forceinline__ f32x4 load_bias4(const float* bias, int row, int N, int n0) {
+    const GBuf bufB = make_gbuf(bias + (size_t)row * N, (uint32_t)N * 4u);
+    const int ln = lane_now(), n = n0 + 4 * ln;
+    return __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < 40 && n < N) ? (uint32_t)n * 4u : kOOB));
+}
+
+// Epilogue of one wave tile (64 x 160 at (mw0, nw0)) through a 32 x 80-column image `stg`.  EPI 0: two column halves per
+// 32-row block (four passes); EPI 1 (fused GEGLU, 80 outputs per row): two passes.
+//
+// vmcnt retires in issue order, so waiting for a LOAD also waits for every STORE issued before it.  The epilogue is
+// therefore written so that no wait ever reaches the stores of the pass in front of it:
+//   * STRAIGHT-LINE code, every load / store a buffer instruction with the hardware range check instead of a predicate:
+//     the compiler's own waits are exact counts (a load inside an exec-masked branch is waited for with vmcnt(0)), and a wave
+//     issues the same number of vector-memory instructions for every tile - the callers' vmcnt arithmetic depends on it;
+//   * the bias (one row: rows_per_batch >= M) does not come from vector memory at all here: the caller fetched the wave's 160
+//     values with ONE load a k-stage ago (`bias4`: lane l holds columns 4 l .. 4 l + 3), they go through a wave-private LDS
+//     strip `bstrip` and every accumulator chunk reads its four with a broadcast ds_read_b128;
+//   * the residual rows of pass p + 1 are requested BEFORE the stores of pass p are issued (into the registers pass p's
+//     residual rows have just left).
+// Bias added in fp32 before the fp16 rounding, residual added to the rounded value: the reference's order
+// (attention.py:293-299) and gemm5's, bit for bit.
+template <int EPI, int RES, int TM>
+__device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5::TN][TM], char* stg, char* bstrip, f32x4 bias4,
+                                              int mw0, int nw0) {
+    using namespace g5;
+    constexpr int H = EPI == 1 ? 1 : 2;               // passes per 32-row block
+    constexpr int NP = TM * H;                        // passes
+    constexpr int CPP = 20 / H;                       // accumulator chunks (i, q) per pass
+    constexpr int CB = 5;                             // chunks per scheduling group
+    constexpr int PITCH = RSG, SEGS = 10, RPI_OUT = 6, NIT = 6;
+    const int M = a.M, N = a.N, ldc = a.ldc, ldr = a.ldr;
+    const float alpha = a.alpha;
+    constexpr bool has_r = EPI == 0 && RES != 0;
+    const bool has_b = a.has_bias;
+    const GBuf bufC = make_gbuf(a.C, a.bytesC);
+    const GBuf bufR = make_gbuf(has_r ? (const void*)a.R : (const void*)a.C, has_r ? a.bytesR : 0u);
+    const int lane = lane_now();
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == 6 -> out of range
+    const int nout = EPI == 1 ? N / 2 : N;
+    if (has_b) {
+        if (lane < 40) *reinterpret_cast<f32x4*>(bstrip + lane * 16) = bias4;
+    }
+    half8_t rres[NIT];     // residual rows of the pass being written (requested one pass ahead, see below)
+    auto load_r = [&](int pass, half8_t* dst) {
+        const int mrow = mw0 + 32 * (pass / H);
+        const int ncol = nw0 + 80 * (pass % H) + seg * 8;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel, m = mrow + r;
+            const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
+            dst[it] = gbuf_ld8(bufR, ok ? ((uint32_t)m * (uint32_t)ldr + (uint32_t)ncol) * 2u : kOOB);
+        }
+    };
+    if (has_r) load_r(0, rres);
+    wave_lds_sync();                                  // the bias strip is readable
+#pragma unroll
+    for (int pass = 0; pass < NP; ++pass) {
+        const int j = pass / H, h = pass % H;
+        const int mrow = mw0 + 32 * j;
+        const int ncol = EPI == 1 ? nw0 / 2 + seg * 8 : nw0 + 80 * h + seg * 8;   // first output column of the lane's segment
+#pragma unroll
+        for (int c0 = 0; c0 < CPP; c0 += CB) {
+            f32x4 bv[CB];
+            if (has_b) {
+#pragma unroll
+                for (int c = 0; c < CB; ++c) {
+                    const int iq = h * CPP + c0 + c;
+                    bv[c] = *reinterpret_cast<const f32x4*>(bstrip + (32 * (iq >> 2) + 8 * (iq & 3) + 4 * lhi) * 4);
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < CB; ++c) {
+                const int iq = h * CPP + c0 + c, i = iq >> 2, q = iq & 3;
+                const int cl = 32 * i + 8 * q + 4 * lhi;   // column within the wave's 160
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * alpha;
+                if (has_b) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += bv[c][e];
+                }
+                if (EPI == 1) {   // fused GEGLU: columns are (h, gate) pairs
+                    half2_t o;
+                    o[0] = to_half(v[0] * gelu_f(v[1]));
+                    o[1] = to_half(v[2] * gelu_f(v[3]));
+                    *reinterpret_cast<half2_t*>(stg + l31 * PITCH + cl) = o;
+                } else {
+                    half4_t o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
+                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + (cl - 80 * h) * 2) = o;
+                }
+            }
+            MC_SCHED_FENCE();   // keeps hipcc from hoisting every chunk's arithmetic to the top (spills: each reload is a vmcnt(0))
+        }
+        wave_lds_sync();
+        // image rows -> registers (+ residual); THEN the next pass's residual rows are requested (into the registers this pass
+        // has just finished with) and only then this pass's stores are issued: a wait for those loads never reaches them
+        half8_t o[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel;
+            o[it] = *reinterpret_cast<const half8_t*>(stg + min(r, 31) * PITCH + seg * 16);
+            if (has_r) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[it][e] = to_half((float)o[it][e] + (float)rres[it][e]);
+            }
+        }
+        MC_SCHED_FENCE();
+        if (has_r && pass + 1 < NP) load_r(pass + 1, rres);
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int r = it * RPI_OUT + rsel, m = mrow + r;
+            const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
+            gbuf_st8(bufC, ok ? ((uint32_t)m * (uint32_t)ldc + (uint32_t)ncol) * 2u : kOOB, o[it]);
+        }
+        wave_lds_sync();   // the image is rewritten by the next pass
+        MC_SCHED_FENCE();
     }
 }
 

@@ -98,7 +98,6 @@ struct G6Args {
     uint32_t bytesS;
 };
 #ifdef MC_EMU
-#define MC_SCHED_FENCE() ((void)0)
 #define G6_ARGS (&args)      // simulator: the parameter is an ordinary object
 typedef const G6Args* g6args_t;
 __device__ inline g6args_t late(const G6Args* a) { return a; }
@@ -106,7 +105,6 @@ __device__ inline g6args_t late(const G6Args* a) { return a; }
 // (the kernarg segment is constant memory: through an address_space(4) pointer held in SGPRs every field is an s_load and stays
 // wave-uniform - through a laundered GENERIC pointer the fields came back as flat loads in VGPRs and every buffer instruction of
 // the epilogue was wrapped in a waterfall loop)
-#define MC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 #define G6_ARGS nullptr      // device: never take the parameter's address (see `late`)
 typedef const G6Args __attribute__((address_space(4)))* g6args_t;
 __device__ __forceinline__ g6args_t late(const G6Args*) {
@@ -115,18 +113,6 @@ __device__ __forceinline__ g6args_t late(const G6Args*) {
     uint64_t v = (uint64_t)__builtin_amdgcn_kernarg_segment_ptr();
     asm volatile("" : "+s"(v));
     return (g6args_t)v;
-}
-#endif
-
-// The lane index, recomputed where it is needed (two VALU instructions) instead of kept: nothing inside the k-loop reads it,
-// so a lane index (or anything derived from it) that lives across the loop is spilled to scratch, and every reload is a
-// scratch_load + s_waitcnt vmcnt(0) - a drain of the operand ring and of the epilogue's stores.  `opaque` keeps hipcc from
-// hoisting the recomputation (and every address that depends on it) back out of the tile loop.
-#ifdef MC_EMU
-__device__ inline int lane_now() { return (int)(threadIdx.x & 63); }
-#else
-__device__ __forceinline__ int lane_now() {
-    return opaque((int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)));
 }
 #endif
 
@@ -172,115 +158,6 @@ __device__ __forceinline__ void flag_wait(uint32_t* f) {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
 #endif
-
-// Epilogue of one wave tile (64 x 160 at (mw0, nw0)) through a 32 x 80-column image `stg`.  EPI 0: two column halves per
-// 32-row block (four passes); EPI 1 (fused GEGLU, 80 outputs per row): two passes.
-//
-// vmcnt retires in issue order, so waiting for a LOAD also waits for every STORE issued before it.  The epilogue is
-// therefore written so that no wait ever reaches the stores of the pass in front of it:
-//   * STRAIGHT-LINE code, every load / store a buffer instruction with the hardware range check instead of a predicate:
-//     the compiler's own waits are exact counts (a load inside an exec-masked branch is waited for with vmcnt(0)), and a wave
-//     issues the same number of vector-memory instructions for every tile - the callers' vmcnt arithmetic depends on it;
-//   * the bias (one row: rows_per_batch >= M) does not come from vector memory at all here: the caller fetched the wave's 160
-//     values with ONE load a k-stage ago (`bias4`: lane l holds columns 4 l .. 4 l + 3), they go through a wave-private LDS
-//     strip `bstrip` and every accumulator chunk reads its four with a broadcast ds_read_b128;
-//   * the residual rows of pass p + 1 are requested BEFORE the stores of pass p are issued (two register sets).
-// Bias added in fp32 before the fp16 rounding, residual added to the rounded value: the reference's order
-// (attention.py:293-299) and gemm5's, bit for bit.
-template <int EPI, int RES, int TM>
-__device__ __forceinline__ void g6_epilogue(const G6Args* ap, f32x16 (&acc)[g5::TN][TM], char* stg, char* bstrip, f32x4 bias4,
-                                            int mw0, int nw0) {
-    using namespace g5;
-    constexpr int H = EPI == 1 ? 1 : 2;               // passes per 32-row block
-    constexpr int NP = TM * H;                        // passes
-    constexpr int CPP = 20 / H;                       // accumulator chunks (i, q) per pass
-    constexpr int CB = 5;                             // chunks per scheduling group
-    constexpr int PITCH = RSG, SEGS = 10, RPI_OUT = 6, NIT = 6;
-    const g6args_t a = late(ap);
-    const int M = a->p.M, N = a->p.N, ldc = a->p.ldc, ldr = a->p.ldr;
-    const float alpha = a->p.alpha;
-    constexpr bool has_r = EPI == 0 && RES != 0;
-    const bool has_b = a->p.bias != nullptr;
-    const GBuf bufC = make_gbuf(a->p.C, a->bytesC);
-    const GBuf bufR = make_gbuf(has_r ? (const void*)a->p.R : (const void*)a->p.C, has_r ? a->bytesR : 0u);
-    const int lane = lane_now();
-    const int l31 = lane & 31, lhi = lane >> 5;
-    const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == 6 -> out of range
-    const int nout = EPI == 1 ? N / 2 : N;
-    if (has_b) {
-        if (lane < 40) *reinterpret_cast<f32x4*>(bstrip + lane * 16) = bias4;
-    }
-    half8_t rres[has_r ? 2 : 1][NIT];
-    auto load_r = [&](int pass, half8_t* dst) {
-        const int mrow = mw0 + 32 * (pass / H);
-        const int ncol = nw0 + 80 * (pass % H) + seg * 8;
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int r = it * RPI_OUT + rsel, m = mrow + r;
-            const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
-            dst[it] = gbuf_ld8(bufR, ok ? ((uint32_t)m * (uint32_t)ldr + (uint32_t)ncol) * 2u : kOOB);
-        }
-    };
-    if (has_r) load_r(0, rres[0]);
-    wave_lds_sync();                                  // the bias strip is readable
-#pragma unroll
-    for (int pass = 0; pass < NP; ++pass) {
-        const int j = pass / H, h = pass % H;
-        const int mrow = mw0 + 32 * j;
-        const int ncol = EPI == 1 ? nw0 / 2 + seg * 8 : nw0 + 80 * h + seg * 8;   // first output column of the lane's segment
-#pragma unroll
-        for (int c0 = 0; c0 < CPP; c0 += CB) {
-            f32x4 bv[CB];
-            if (has_b) {
-#pragma unroll
-                for (int c = 0; c < CB; ++c) {
-                    const int iq = h * CPP + c0 + c;
-                    bv[c] = *reinterpret_cast<const f32x4*>(bstrip + (32 * (iq >> 2) + 8 * (iq & 3) + 4 * lhi) * 4);
-                }
-            }
-#pragma unroll
-            for (int c = 0; c < CB; ++c) {
-                const int iq = h * CPP + c0 + c, i = iq >> 2, q = iq & 3;
-                const int cl = 32 * i + 8 * q + 4 * lhi;   // column within the wave's 160
-                f32x4 v;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * q + e] * alpha;
-                if (has_b) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += bv[c][e];
-                }
-                if (EPI == 1) {   // fused GEGLU: columns are (h, gate) pairs
-                    half2_t o;
-                    o[0] = to_half(v[0] * gelu_f(v[1]));
-                    o[1] = to_half(v[2] * gelu_f(v[3]));
-                    *reinterpret_cast<half2_t*>(stg + l31 * PITCH + cl) = o;
-                } else {
-                    half4_t o;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
-                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + (cl - 80 * h) * 2) = o;
-                }
-            }
-            MC_SCHED_FENCE();   // keeps hipcc from hoisting every chunk's arithmetic to the top (spills: each reload is a vmcnt(0))
-        }
-        wave_lds_sync();
-        if (has_r && pass + 1 < NP) load_r(pass + 1, rres[has_r ? (pass + 1) & 1 : 0]);   // in front of this pass's stores
-        MC_SCHED_FENCE();
-#pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int r = it * RPI_OUT + rsel, m = mrow + r;
-            const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
-            half8_t o = *reinterpret_cast<const half8_t*>(stg + min(r, 31) * PITCH + seg * 16);
-            if (has_r) {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) o[e] = to_half((float)o[e] + (float)rres[has_r ? pass & 1 : 0][it][e]);
-            }
-            gbuf_st8(bufC, ok ? ((uint32_t)m * (uint32_t)ldc + (uint32_t)ncol) * 2u : kOOB, o);
-        }
-        wave_lds_sync();   // the image is rewritten by the next pass
-        MC_SCHED_FENCE();
-    }
-}
 
 template <int EPI, int RES, int VAR, int SK>
 __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
@@ -537,6 +414,14 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
         }
     };
 
+    auto epi_args = [&]() {          // fetched where the epilogue runs (see `late`)
+        const g6args_t q = late(G6_ARGS);
+        EpiArgs e;
+        e.C = q->p.C; e.R = q->p.R; e.M = q->p.M; e.N = q->p.N; e.ldc = q->p.ldc; e.ldr = q->p.ldr; e.alpha = q->p.alpha;
+        e.bytesC = q->bytesC; e.bytesR = q->bytesR; e.has_bias = q->p.bias != nullptr;
+        return e;
+    };
+
     auto run = [&](auto ga_tag) {
         constexpr bool GA = decltype(ga_tag)::value;
         constexpr int L = GA ? LA : LB;
@@ -592,11 +477,7 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             {
                 const g6args_t q = late(G6_ARGS);
-                if (q->p.bias) {
-                    const GBuf bufB = make_gbuf(q->p.bias, q->bytesB);
-                    const int ln = lane_now(), n = c_n0 + wn0 + 4 * ln;
-                    bias4 = __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < 40 && n < q->p.N) ? (uint32_t)n * 4u : kOOB));
-                }
+                if (q->p.bias) bias4 = load_bias4(q->p.bias, 0, q->p.N, c_n0 + wn0);
             }
             stage(X0());
             // tile finished.  Its last stage's slot (`buf` was advanced past it) is free: every wave read it before the last
@@ -629,7 +510,7 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
                     finish = true;
                     break;
                 }
-                g6_epilogue<EPI, RES, TM>(G6_ARGS, acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
+                tile_epilogue<EPI, RES, TM>(epi_args(), acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
             }
             if (!l_valid) break;            // the load side ran off the list: nothing real is in flight
             if (ask) lds_st32(handover, (uint32_t)nslots + ticket);
@@ -660,12 +541,8 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
             gather_partials(c_cnt);
             f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
             const g6args_t q = late(G6_ARGS);
-            if (q->p.bias) {
-                const GBuf bufB = make_gbuf(q->p.bias, q->bytesB);
-                const int ln = lane_now(), n = c_n0 + wn0 + 4 * ln;
-                bias4 = __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < 40 && n < q->p.N) ? (uint32_t)n * 4u : kOOB));
-            }
-            g6_epilogue<EPI, RES, TM>(G6_ARGS, acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
+            if (q->p.bias) bias4 = load_bias4(q->p.bias, 0, q->p.N, c_n0 + wn0);
+            tile_epilogue<EPI, RES, TM>(epi_args(), acc, img, bstrip, bias4, c_m0 + wm0, c_n0 + wn0);
         }
     };
     if (grpA) run(std::true_type()); else run(std::false_type());

@@ -68,6 +68,8 @@ __device__ inline int shfl(int v, int src) { return hipemu::shfl(v, src); }
 __device__ inline f32x4 mfma16(half4_t a, half4_t b, f32x4 c) { return hipemu::mfma_16x16x16(a, b, c); }
 __device__ inline f32x16 mfma32(half8_t a, half8_t b, f32x16 c) { return hipemu::mfma_32x32x16(a, b, c); }
 __device__ inline f32x4 mfma16k32(half8_t a, half8_t b, f32x4 c) { return hipemu::mfma_16x16x32(a, b, c); }
+__device__ inline void mfma32_agpr(f32x16& c, half8_t a, half8_t b) { c = hipemu::mfma_32x32x16(a, b, c); }
+__device__ inline void mfma32_vgpr(f32x16& c, half8_t a, half8_t b) { c = hipemu::mfma_32x32x16(a, b, c); }
 __device__ inline float fast_exp(float x) { return expf(x); }
 __device__ inline float fast_rsqrt(float x) { return 1.0f / sqrtf(x); }
 #define MC_DYN_SMEM(name) char* name = hipemu::dyn_smem()
@@ -95,6 +97,16 @@ __device__ __forceinline__ f32x16 mfma32(half8_t a, half8_t b, f32x16 c) {
 // D[16x16] += A[16x32] * B[32x16]; lane l: a = A[l&15][8*(l>>4)+j], b = B[8*(l>>4)+j][l&15], c as mfma16.
 __device__ __forceinline__ f32x4 mfma16k32(half8_t a, half8_t b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+// The same MFMA with the accumulator's register class chosen by the CALLER (inline asm: "a" = AGPR, "v" = VGPR).  A wave that owns
+// a whole SIMD may use 256 + 256 registers, but hipcc puts every accumulator of a kernel into ONE class: 320 accumulators
+// (128 x 160 wave tile) spilled 468 registers.  With four of five column blocks in AGPRs and one in VGPRs they fit.  No
+// instruction reads an accumulator closer than a whole k-slice (20 MFMAs) behind its write: no MFMA hazard to pad.
+__device__ __forceinline__ void mfma32_agpr(f32x16& c, half8_t a, half8_t b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma32_vgpr(f32x16& c, half8_t a, half8_t b) {
+    asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(c) : "v"(a), "v"(b));
 }
 __device__ __forceinline__ float fast_exp(float x) { return __expf(x); }
 __device__ __forceinline__ float fast_rsqrt(float x) { return rsqrtf(x); }

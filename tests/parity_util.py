@@ -23,10 +23,13 @@ TOL_FWD, TOL_GRAD, TOL_LOSS = 5e-3, 2e-2, 2e-3
 # at configs 1 / 2 / 4 and F = 32 -> 1.2e-2; 1.13e-2 at config 5's real size (|grad| <= 6e-6 there) -> 1.5e-2.  TOL_GRAD stays
 # the bound of the tiny simulator cases (few elements: the relative L2 of a 4 x 4 map is noisier).
 TOL_GRAD_FULLSIZE, TOL_GRAD_CONFIG5 = 1.2e-2, 1.5e-2
+# Round 6 (ADVICE): the most an fp16 witness may loosen the gradient bound of the stress cases - 2x the worst engine error ever
+# measured on them (1.64e-2, the BOS-token case)
+TOL_GRAD_WITNESS_CAP = 3.3e-2
 TIE_GAP = 5e-4                                      # a flipped arg-max must be a tie at this level of the fp32 oracle's P
 #                                                     (round 4: 1e-3 -> 5e-4; the worst gap ever measured is 3.4e-4)
 MAX_FLIP_FRACTION = 5e-3
-REPORT_FILE = "parity_r05.json"
+REPORT_FILE = "parity_r06.json"
 
 _REPORT = {}
 
@@ -184,7 +187,10 @@ def check_guided_step(eng, smp, sdo, cfg, lat, text, rep_ref, step_index, key, c
         t_eps = max(TOL_FWD, witness_factor * wit["eps_c"])
         t_lat = max(TOL_FWD, witness_factor * wit["latents"])
         t_loss = max(TOL_LOSS, witness_factor * wit["loss"])
-        tol_grad = max(tol_grad, 0.5 * wit["grad"]) if wit["grad"] == wit["grad"] else tol_grad
+        # the fp16 witness's gradient is 0.10-0.14 off fp32 on the ill-conditioned cases (underflow): half of THAT would admit a 4x
+        # regression of the engine (measured 0.006-0.016).  The witness may loosen the bound only up to TOL_GRAD_WITNESS_CAP.
+        if wit["grad"] == wit["grad"]:
+            tol_grad = max(tol_grad, min(0.5 * wit["grad"], TOL_GRAD_WITNESS_CAP))
     assert e["eps_c"] < t_eps and e["eps_u"] < t_eps, e
     assert e["loss"] < t_loss, e
     assert e["grad"] < tol_grad, e
@@ -255,3 +261,81 @@ def check_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, tol, first=0, last=N
     assert torch.isfinite(x.float()).all()
     assert max(drift) < tol, drift
     return drift
+
+
+# ---- round 6: guidance that MATTERS ----------------------------------------------------------------------------------------
+def stress_weights(sd, variant, dev, seed=99):
+    """The stress variants of tests/test_fullsize_parity.py as a weight transform (seeded; returns the new state dict and the
+    counts of what was touched): "outlier_channels" - 4 channels of every GroupNorm / LayerNorm gain x 12 and two output channels
+    of every FeedForward x 6; "sharp_attention" - every to_q / to_k x 2.5 (logits span 6 x what N(0, init) gives: the temporal maps
+    turn nearly one-hot and the MotionClone loss / gradient become large); "bos_token" - weights unchanged (the text is)."""
+    g = torch.Generator(device=dev).manual_seed(seed)
+    sd2 = {}
+    n = dict(norm=0, ff=0, qk=0)
+    for k, v in sd.items():
+        v = v.clone()
+        if variant == "outlier_channels":
+            if k.endswith("weight") and v.dim() == 1 and ("norm" in k):
+                idx = torch.randperm(v.numel(), generator=g, device=dev)[:4]
+                v[idx] = v[idx] * 12.0
+                n["norm"] += 1
+            elif k.endswith("ff.net.2.weight"):
+                idx = torch.randperm(v.shape[0], generator=g, device=dev)[:2]
+                v[idx] = v[idx] * 6.0
+                n["ff"] += 1
+        elif variant == "sharp_attention" and (k.endswith("to_q.weight") or k.endswith("to_k.weight")):
+            v = v * 2.5
+            n["qk"] += 1
+        sd2[k] = v
+    return sd2, n
+
+
+def oracle_guided_step_scaled(sdo, cfg, x, i, ts, text, rep, hp, grad_factor):
+    """The oracle's guided step with the MotionClone gradient multiplied by `grad_factor` before the DDIM update (1 = the
+    reference; 0.5 = what a factor-2 error anywhere in the guidance gradient path would do; 0 = guidance dropped)."""
+    nxt, aux = G.guided_step(sdo, cfg, x, i, ts, text, rep, hp)
+    if grad_factor != 1.0:
+        eps = aux["eps_c"] + hp["cfg_scale"] * (aux["eps_c"] - aux["eps_u"])
+        nxt = G.ddim_step(G.alphas_cumprod(), ts, i, eps, x, score=grad_factor * aux["grad"])
+    return nxt, aux
+
+
+def check_guidance_sensitive_loop(eng, smp, sdo, cfg, lat, text, rep_ref, key, last=None, margin=0.5, min_visibility=3e-3):
+    """Steps [0, last) with FOUR trajectories from the same start: the engine, the fp32 oracle, the oracle with the guidance
+    gradient HALVED (a factor-2 error of the gradient path) and the oracle with guidance DROPPED.  The engine must stay closer to
+    the oracle than `margin` x the halved-gradient trajectory does - at every guided step from the third on and at the end - so a
+    gradient path that is off by 2x FAILS; and the halved trajectory must be at least `min_visibility` away (otherwise the weights
+    make guidance invisible and the test proves nothing: that is an error of the test, not a pass)."""
+    ts = G.uneven_timesteps(smp.N, smp.G, smp_guidance_scale(smp))
+    hp = dict(HP, guidance_steps=smp.G)
+    rep_dev = eng.prepare_representation(rep_ref)
+    last = smp.N if last is None else last
+    xr = lat.float()
+    xh, x0g, x = xr.clone(), xr.clone(), xr.half()
+    rows = []
+    for i in range(last):
+        x = smp.step(x, i, text, rep_dev)
+        with oracle_mode(lat.device):
+            if i < smp.G:
+                xr, aux = oracle_guided_step_scaled(sdo, cfg, xr, i, ts, text.float(), rep_ref, hp, 1.0)
+                xh, _ = oracle_guided_step_scaled(sdo, cfg, xh, i, ts, text.float(), rep_ref, hp, 0.5)
+                x0g, _ = oracle_guided_step_scaled(sdo, cfg, x0g, i, ts, text.float(), rep_ref, hp, 0.0)
+                eps = aux["eps_c"] + hp["cfg_scale"] * (aux["eps_c"] - aux["eps_u"])
+                a_t = float(G.alphas_cumprod()[int(ts[i])])
+                score_over_eps = float(((1 - a_t) ** 0.5 * aux["grad"]).norm() / eps.norm())
+            else:
+                xr, _ = G.plain_step_full(sdo, cfg, xr, i, ts, text.float(), hp["cfg_scale"])
+                xh, _ = G.plain_step_full(sdo, cfg, xh, i, ts, text.float(), hp["cfg_scale"])
+                x0g, _ = G.plain_step_full(sdo, cfg, x0g, i, ts, text.float(), hp["cfg_scale"])
+                score_over_eps = None
+        rows.append(dict(step=i, engine=rel(x, xr), half_gradient=rel(xh, xr), no_guidance=rel(x0g, xr),
+                         score_over_eps=score_over_eps))
+    report(key, sensitive_loop=[{k: (round(v, 6) if isinstance(v, float) else v) for k, v in r.items()} for r in rows],
+           loop_schedule=[smp.N, smp.G], loop_steps=[0, last])
+    assert torch.isfinite(x.float()).all()
+    vis = max(r["half_gradient"] for r in rows)
+    assert vis >= min_visibility, "guidance is numerically invisible with these weights (half-gradient trajectory %.2e away)" % vis
+    for r in rows:
+        if (2 <= r["step"] < smp.G) or r["step"] == last - 1:
+            assert r["engine"] < margin * r["half_gradient"], r
+    return rows

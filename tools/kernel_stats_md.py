@@ -74,7 +74,19 @@ def durations_json(stats_path, trace_dir, videos, vpm, tag):
         code = subprocess.run(["git", "rev-parse", "--short", "HEAD"], stdout=subprocess.PIPE, text=True).stdout.strip() or None
     except Exception:   # noqa: BLE001
         code = None
-    return dict(regime="hipGraph replay, three videos in flight, no probe videos: `python bench.py --no-cpu-baseline --no-vae "
+    # what bench.py's roofline_timed checks: the source stamp of the library the traced run loaded (build.py writes it next to the
+    # .so) and the GPU it ran on - a trace of other code or another device is refused there
+    here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    try:
+        lib_stamp = open(os.path.join(here, "motionclone_amd", "csrc", "libmotionclone_hip.so.stamp")).read().strip()
+    except OSError:
+        lib_stamp = None
+    try:
+        import torch
+        device = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
+    except Exception:   # noqa: BLE001
+        device = None
+    return dict(lib_stamp=lib_stamp, device=device, regime="hipGraph replay, three videos in flight, no probe videos: `python bench.py --no-cpu-baseline --no-vae "
                        "--no-probe --steps 6 --warmup 3` under rocprofv3 --kernel-trace --stats (%s)" % tag, videos_in_trace=videos, videos_per_min_under_profiler=vpm,
                 total_kernel_s=total, overlap=overlap, code=code, kernels=kern)
 
