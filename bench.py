@@ -398,6 +398,8 @@ def main():
     ap.add_argument("--no-graphs", action="store_true", help="time the eager launch sequence instead of the per-step hipGraphs")
     ap.add_argument("--gemm-lanes", type=int, default=0, help="value handed to ops.set_gemm_share (0 = the number of videos in flight)")
     ap.add_argument("--shapes-out", default=None, help="write the per-(kernel, shape) GEMM time table of the probe video to this JSON file")
+    ap.add_argument("--no-gn-epilogue", action="store_true", help="A/B: GroupNorm statistics always from their own pass over the tensor "
+                    "(round 5) instead of the producing GEMM's epilogue (mc_gemm_gnstats_f16)")
     ap.add_argument("--no-norm-fusion", action="store_true", help="A/B: LayerNorm / GroupNorm as separate launches in front of the "
                     "K = 320 GEMMs (the round-3 launch sequence) instead of mc_norm_gemm_f16")
     ap.add_argument("--no-shared-prefix", action="store_true", help="A/B: feed the UNet the duplicated CFG batch [x | x] as rounds 1-4 did, "
@@ -443,6 +445,8 @@ def main():
         # barrier: a timeout well past that post-work, so RCCL's watchdog never tears the job down before the line is printed
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=datetime.timedelta(hours=2))
     lib.load()  # fails loudly if the gfx950 library is missing
+    if args.no_gn_epilogue:
+        ops.GN_FROM_EPILOGUE = False
     if args.no_norm_fusion:
         ops.NORM_GEMM_MIN_ROWS = 1 << 62
     ops.TILELOOP = {"auto": None, "off": False, "all": True}[args.tileloop]

@@ -65,6 +65,20 @@ int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const voi
                 int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
                 int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, void* stream);
 
+/* mc_gemm_f16 that ALSO leaves the GroupNorm(32) partial sums of its OUTPUT (round 6): (sum, sum of squares) of the rounded fp16
+ * values per (frame, chunk of 64 or 32 rows, group), written by the epilogue of the one-pass 256x320 / 128x320 ring kernels, so
+ * that the GroupNorm reading C next needs no statistics pass (one launch and one read of the tensor less per GroupNorm:
+ * resnet.py:197 after conv1; resnet.py:186 / attention.py:105 / motion_module.py:145 after conv2 + shortcut).
+ *   gn_partial: float[(M / gn_hw) * (gn_hw / 32) * 64] = mc_workspace_bytes_gemm_gnstats(M / gn_hw, gn_hw); gn_hw: tokens per frame.
+ * Returns the chunk height used (64 or 32: hand gn_hw / it to mc_groupnorm_fwd_partial_f16 as `pchunks`), or MC_ERR_UNSUPPORTED
+ * (-2) with NOTHING launched - the library's own choice for the problem is another kernel (split-K, K = 320 streaming, small
+ * tiles), N / 32 is not 10 / 20 / 40, or a wave tile would straddle frames: call mc_gemm_f16 + mc_groupnorm_fwd_f16. */
+long mc_workspace_bytes_gemm_gnstats(int frames, int hw);
+int mc_gemm_gnstats_f16(const void* A, const void* A2, const void* W, void* C, const void* R, const float* bias,
+                        int M, int N, int K, int lda, int lda2, int ldc, int ldr, int c1, int ctot, int mode,
+                        int Hs, int Ws, int Ho, int Wo, int rows_per_batch, float alpha, int flags, float* gn_partial, int gn_hw,
+                        void* stream);
+
 /* Persistent tile loop over the 256x320 tile (gemm6.hip, round 6): the same product as mc_gemm_f16 (DENSE, bit-identical to
  * its 256x320 kernel) with ONE workgroup per CU walking the output tiles and the LDS operand ring running through tile
  * boundaries - for the Linear layers (diffusers FeedForward at attention.py:211,288 / motion_module.py:209,222; to_q|k|v and
@@ -112,8 +126,9 @@ int mc_gemm_debug_buffer(void* device_buffer);   /* bit 16: in-kernel cycle stam
  *   kind 2: GroupNorm(32 groups, NO activation) over frames of hw tokens (= mc_groupnorm_fwd_f16(silu = 0) then mc_gemm_f16;
  *           Transformer3DModel.norm + proj_in, attention.py:61-65,105-117; motion_module.py:112-113,145-151); hw % 256 == 0;
  *           partial: workspace of mc_workspace_bytes_groupnorm(M / hw, hw); stats: float[(M / hw) * 32 * 2] out (for the backward).
- * flags: 0x200 = fused GEGLU epilogue (as mc_gemm_f16).  Returns MC_ERR_UNSUPPORTED (-2) for shapes outside that kernel:
- * the caller then issues the two-launch form. */
+ * flags: 0x200 = fused GEGLU epilogue (as mc_gemm_f16); bits 16-23 (kind 2) = n > 0: `partial` already holds the sums of A, written
+ * with n chunks per frame by the kernel that produced A (mc_gemm_gnstats_f16) - no statistics pass.  Returns MC_ERR_UNSUPPORTED
+ * (-2) for shapes outside that kernel: the caller then issues the two-launch form. */
 int mc_norm_gemm_f16(const void* A, const void* W, void* C, const float* bias, int M, int N, int K, int lda, int ldc,
                      int kind, const float* gamma, const float* beta, const float* pe, int hw, int nframes_pe, float eps,
                      float* stats, float* partial, int flags, void* stream);
@@ -145,6 +160,13 @@ int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int ldb, int c
 int mc_groupnorm_fwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw, float eps,
                          float* partial, float* stats, const float* gamma, const float* beta, void* out, int ldo, int silu,
                          void* stream);
+/* mc_groupnorm_fwd_f16 WITHOUT its statistics pass (round 6; single source, ONE launch): `partial` holds the per-chunk (sum, sum of
+ * squares) of every (frame, group) as left by the epilogue of the kernel that produced `a` - mc_gemm_gnstats_f16 - with
+ * `pchunks` = hw / (the chunk height that call returned) chunks per frame.  resnet.py:197-199 (norm2 after conv1),
+ * resnet.py:186, attention.py:105 and motion_module.py:145 after a block's conv2 + shortcut. */
+int mc_groupnorm_fwd_partial_f16(const void* a, int lda, int ctot, int frames, int hw, float eps, const float* partial,
+                                 int pchunks, float* stats, const float* gamma, const float* beta, void* out, int ldo,
+                                 int silu, void* stream);
 /* data-gradient (autograd of the above; reference motionclone_functions.py:236). bstats: float[frames*64] */
 int mc_groupnorm_bwd_f16(const void* a, const void* b, int lda, int ldb, int c1, int ctot, int frames, int hw,
                          const void* dz, int lddz, const float* stats, const float* gamma, const float* beta,

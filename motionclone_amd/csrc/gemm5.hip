@@ -28,7 +28,7 @@ namespace mc {
 // VAR (timing experiments, tools/gemm5_bench.py): bit 0 = STAGGER the LDS-DMA issue between the two waves of a SIMD (waves 0-3
 // in the first half of a stage, waves 4-7 in the second; measured 1-8 % slower than everybody in the first half, which is the
 // default), bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
-template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS, int RES = 0>
+template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS, int RES = 0, int GNS = 0>
 __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
                                                                           uint32_t bytesW, int tilesM, int tilesN, int sm, int sn) {
     using g5::TN; using g5::BKT; using g5::RPI; using g5::STG; using g5::lds_off32;
@@ -364,8 +364,11 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void ge
         e.has_bias = p.bias != nullptr;
         char* img = smem + wave * (32 * g5::RSG);                       // 32 rows x 80 columns per wave
         char* bstrip = smem + NW * (32 * g5::RSG) + wave * 640;         // 160 fp32 per wave
-        tile_epilogue<EPI, RES, TM>(e, acc, img, bstrip, bias4, m0 + wm0, n0 + wn0);   // RES: with a residual (its own instantiation:
-        return;                                                                          // as a run-time branch the pair spilled)
+        if constexpr (GNS != 0) {
+            e.gn_partial = p.gn_partial; e.gn_hw = p.gn_hw; e.gn_cpg = p.N / 32;
+        }
+        tile_epilogue<EPI, RES, TM, GNS>(e, acc, img, bstrip, bias4, m0 + wm0, n0 + wn0);   // RES: with a residual (its own
+        return;                                                      // instantiation: as a run-time branch the pair spilled)
     }
 }
 
@@ -407,11 +410,11 @@ __global__ __launch_bounds__(64) void splitk_reduce5_kernel(GemmParams p, int ti
     g5_epilogue<0, TM>(p, acc, smem, tm * (128 * TM) + wr * (32 * TM), tn * BN + wc * 160, lane);
 }
 
-template <int MODE, int EPI, int VAR, int BM, int BN, int NW, int NS, int RES>
+template <int MODE, int EPI, int VAR, int BM, int BN, int NW, int NS, int RES, int GNS = 0>
 static int launch5r(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
     using T = g5::Tile<BM, BN, NW, NS>;
     int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN;
-    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS, RES>, T::SMEM);
+    allow_big_smem(gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS, RES, GNS>, T::SMEM);
     // super-tile of the XCD-local tile order: sn divides the N-tiles, sm x sn ~ the workgroups an XCD holds at a time (32 CUs x
     // 1 or 2), least operand rows per tile
     const int rows_per_xcd = (tM + 7) / 8;
@@ -432,7 +435,7 @@ static int launch5r(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW,
     }
     const int groups = (rows_per_xcd + sm - 1) / sm;
     dim3 grid((unsigned)(groups * sm * 8 * tN), (unsigned)p.splits);
-    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS, RES>), grid, dim3(T::NTH), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
+    MC_LAUNCH((gemm5_kernel<MODE, EPI, VAR, BM, BN, NW, NS, RES, GNS>), grid, dim3(T::NTH), T::SMEM, stream, p, bA, bA2, bW, tM, tN, sm, sn);
     if (MC_LAST_ERROR()) return MC_ERR_LAUNCH;
     if constexpr (NW == 8 && BN == g5::BN) {   // (the split-K slabs / reduce pass are laid out for the 8-wave geometries)
         if (p.ws) {
@@ -445,6 +448,13 @@ static int launch5r(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW,
 
 template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS>
 static int launch5(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t bW, hipStream_t stream) {
+    if constexpr (EPI == 0 && VAR == 0 && NW == 8 && BN == g5::BN && (MODE == DENSE || MODE == CONV_S1)) {
+        if (p.gn_partial) {    // statistics of the output for the GroupNorm that reads it (gemm5_dispatch has checked the shape)
+            if (p.R) return launch5r<MODE, EPI, VAR, BM, BN, NW, NS, 1, 1>(p, bA, bA2, bW, stream);
+            return launch5r<MODE, EPI, VAR, BM, BN, NW, NS, 0, 1>(p, bA, bA2, bW, stream);
+        }
+    }
+    if (p.gn_partial) return MC_ERR_UNSUPPORTED;
     if constexpr (EPI == 0) {
         if (p.R && !p.ws) return launch5r<MODE, EPI, VAR, BM, BN, NW, NS, 1>(p, bA, bA2, bW, stream);
     }
@@ -495,6 +505,13 @@ int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStre
     if (var == 1 || var == 2 || var == 3 || var > 6) return MC_ERR_UNSUPPORTED;
     if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
     if (p.epi == 1 && (p.N & 15)) return MC_ERR_UNSUPPORTED;
+    if (p.gn_partial) {
+        // GroupNorm statistics from the epilogue: one pass, whole groups per wave (160 columns), a wave tile inside one frame
+        const int rows = var == 4 ? 32 : 64, cpg = p.N / 32;
+        if (p.ws || p.epi || (var != 0 && var != 4) || (mode != DENSE && mode != CONV_S1)) return MC_ERR_UNSUPPORTED;
+        if (p.N % 160 || p.N % 32 || (cpg != 10 && cpg != 20 && cpg != 40)) return MC_ERR_UNSUPPORTED;   // SD-1.5's 320 / 640 / 1280
+        if (p.gn_hw <= 0 || p.gn_hw % rows || p.M % p.gn_hw) return MC_ERR_UNSUPPORTED;
+    }
     if (!p.ws) {
         // the one-pass epilogue (tile_epilogue) reads ONE bias row per tile and addresses C / R through 2 GiB descriptors
         const int bm = var == 4 ? 128 : 256;

@@ -147,6 +147,11 @@ struct EpiArgs {
     float alpha;
     uint32_t bytesC, bytesR;
     bool has_bias;
+    // GNS epilogues only: GroupNorm partial sums of the tile's OUTPUT for the norm that reads it next (resnet.py:197, attention.py:105,
+    // motion_module.py:145): float[frame][chunk][32 groups][2] with chunks of 32 TM rows, gn_hw tokens per frame, gn_cpg channels
+    // per group (N / 32)
+    float* gn_partial;
+    int gn_hw, gn_cpg;
 };
 
 // the wave's 160 bias values of output columns [n0, n0 + 160) of bias row `row` (row-major [rows][N] fp32): lane l < 40 gets
@@ -172,9 +177,18 @@ __device__ __forceinline__ f32x4 load_bias4(const float* bias, int row, int N, i
 //     residual rows have just left).
 // Bias added in fp32 before the fp16 rounding, residual added to the rounded value: the reference's order
 // (attention.py:293-299) and gemm5's, bit for bit.
-template <int EPI, int RES, int TM>
+//
+// GNS (round 6): the wave also leaves the GroupNorm statistics of what it stores - (sum, sum of squares) of the ROUNDED fp16
+// outputs (after the residual: the values the next GroupNorm reads) per group over the wave tile's 32 TM rows, written to
+// gn_partial[frame][chunk][group] where gn_block_stats of the consuming kernel adds the chunks in order: the statistics pass over
+// the tensor (gn_partial_kernel: one launch and one read of the tensor per GroupNorm) is gone.  Requires that a wave tile
+// lies inside one frame (hw % (32 TM) == 0, M % hw == 0) and that its 160 columns hold whole groups (160 % cpg == 0, cpg even):
+// the dispatcher checks.  Two fp16 columns per v_dot2_f32_f16; lanes -> groups through the (by then idle) image; every
+// (frame, chunk, group) slot has ONE writer and the additions have a fixed order: deterministic.
+template <int EPI, int RES, int TM, int GNS = 0>
 __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5::TN][TM], char* stg, char* bstrip, f32x4 bias4,
                                               int mw0, int nw0) {
+    static_assert(!GNS || EPI == 0, "statistics of the plain epilogue only");
     using namespace g5;
     constexpr int H = EPI == 1 ? 1 : 2;               // passes per 32-row block
     constexpr int NP = TM * H;                        // passes
@@ -194,6 +208,11 @@ __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5
     if (has_b) {
         if (lane < 40) *reinterpret_cast<f32x4*>(bstrip + lane * 16) = bias4;
     }
+    float gsum[H][4], gsq[H][4];   // GNS: column-pair sums of the lane's 8 columns per column half, over both 32-row blocks
+#pragma unroll
+    for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) gsum[hh][e] = gsq[hh][e] = 0.f;
     half8_t rres[NIT];     // residual rows of the pass being written (requested one pass ahead, see below)
     auto load_r = [&](int pass, half8_t* dst) {
         const int mrow = mw0 + 32 * (pass / H);
@@ -267,9 +286,62 @@ __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5
             const int r = it * RPI_OUT + rsel, m = mrow + r;
             const bool ok = rsel < RPI_OUT && r < 32 && m < M && ncol < nout;
             gbuf_st8(bufC, ok ? ((uint32_t)m * (uint32_t)ldc + (uint32_t)ncol) * 2u : kOOB, o[it]);
+            if constexpr (GNS != 0) {
+                half2_t one2;
+                one2[0] = one2[1] = (half_t)1.0f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    half2_t v;
+                    v[0] = ok ? o[it][2 * e] : (half_t)0.0f;
+                    v[1] = ok ? o[it][2 * e + 1] : (half_t)0.0f;
+                    gsum[h][e] = dot2acc(v, one2, gsum[h][e]);
+                    gsq[h][e] = dot2acc(v, v, gsq[h][e]);
+                }
+            }
         }
         wave_lds_sync();   // the image is rewritten by the next pass
         MC_SCHED_FENCE();
+    }
+    if constexpr (GNS != 0) {
+        // lanes -> groups: every lane leaves its 8 pair sums in the image as [rsel][pair 0 .. 79] (sum, sumsq); then 64 / G lanes
+        // per group (G = 160 / cpg groups in the wave's columns) add a strided share of the group's 6 x cpg / 2 entries in a fixed
+        // order and a butterfly joins them.  (The image is idle: the last pass has been read back and waited for.)
+        f32x2* red = reinterpret_cast<f32x2*>(stg);
+        if (rsel < RPI_OUT) {
+#pragma unroll
+            for (int hh = 0; hh < H; ++hh)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    f32x2 pr;
+                    pr[0] = gsum[hh][e];
+                    pr[1] = gsq[hh][e];
+                    red[rsel * 80 + 40 * hh + 4 * seg + e] = pr;
+                }
+        }
+        wave_lds_sync();
+        const int ppg = a.gn_cpg >> 1;            // column pairs per group: 5 / 10 / 20
+        const int G = 80 / ppg;                   // groups in the wave's 160 columns: 16 / 8 / 4
+        const int LPG = 64 / G;                   // lanes per group: 4 / 8 / 16
+        const int g = lane / LPG, sub = lane % LPG;
+        const int items = RPI_OUT * ppg;          // (rsel, pair) entries of one group
+        float s1 = 0.f, s2 = 0.f;
+        for (int it = sub; it < items; it += LPG) {
+            const f32x2 v = red[(it / ppg) * 80 + g * ppg + it % ppg];
+            s1 += v[0];
+            s2 += v[1];
+        }
+        for (int mk = 1; mk < LPG; mk <<= 1) {
+            s1 += shfl_xor(s1, mk);
+            s2 += shfl_xor(s2, mk);
+        }
+        if (sub == 0 && mw0 < M) {
+            const int rows = 32 * TM, frame = mw0 / a.gn_hw, chunk = (mw0 % a.gn_hw) / rows, pch = a.gn_hw / rows;
+            f32x2 pr;
+            pr[0] = s1;
+            pr[1] = s2;
+            reinterpret_cast<f32x2*>(a.gn_partial)[((size_t)frame * pch + chunk) * 32 + nw0 / a.gn_cpg + g] = pr;
+        }
+        wave_lds_sync();
     }
 }
 

@@ -62,6 +62,11 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         g_last_kernel = 4;
         return mode == DENSE ? gemm4_dispatch(p, nsplit, s) : MC_ERR_UNSUPPORTED;
     }
+    if (p.gn_partial && (big_cfg == 11 || big_cfg == 15) && !tile && !deep) {   // forced geometry (tests): 256- / 128-row tiles
+        const int rc5 = gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);
+        g_last_kernel = big_cfg == 15 ? 54 : 51;
+        return rc5 == MC_OK ? (big_cfg == 11 ? 64 : 32) : rc5;
+    }
     if (big_cfg >= 11) {   // 11 = gemm5, 12-14 = schedule experiments, 15 = 128-row tiles
         g_last_kernel = big_cfg == 15 ? 54 : 51;
         return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);
@@ -74,6 +79,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         g_last_kernel = 56;
         return gemm5_dispatch(p, mode, 5, rowsA, s);
     }
+    if (p.gn_partial && (big_cfg || tile || deep)) return MC_ERR_UNSUPPORTED;   // statistics: the library's own choice only
     static const int no_g5 = MC_ENV_INT("MC_NO_GEMM5", 0);     // A/B, tools build only
     static const int g5_var = MC_ENV_INT("MC_GEMM5_VAR", 0);   // A/B, tools build only
     const bool automatic = !big_cfg && !tile && !deep;   // an explicit cfg = 1 still means gemm3 (tests, A/B tools)
@@ -84,6 +90,7 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         // smaller problems stay on the 128x128 / 64x64 tiles
         static const int no_g4 = MC_ENV_INT("MC_NO_GEMM4", 0);   // diagnosis, tools build only
         if (!no_g4 && mode == DENSE && p.K == 320 && !p.A2 && (M >= 98304 || (M >= 32768 && N >= 640))) {
+            if (p.gn_partial) return MC_ERR_UNSUPPORTED;     // (the streaming kernel's epilogue leaves no statistics)
             int rc4 = gemm4_dispatch(p, 0, s);
             g_last_kernel = 4;
             if (rc4 != MC_ERR_UNSUPPORTED) return rc4;
@@ -108,6 +115,14 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     // Measured inside the step loop (profiles/r04_gemm5_2wg.md): ONE video in flight +1.0 ... +2.8 % (rule 4 / rule 3), THREE
     // in flight -0.3 ... -2 % (the other streams already fill the prologue / epilogue gaps, and the geometry moves 1.44x the
     // operand bytes per MFMA) - so the default (-1) takes rule 4 only when the caller keeps a single launch sequence in flight
+    if (p.gn_partial) {
+        // GroupNorm statistics of the output from the epilogue (mc_gemm_gnstats_f16): the one-pass gemm5 kernels only; the return
+        // value is the chunk height the statistics were written with (64 = 256-row tiles, 32 = 128-row tiles)
+        if (no_g5 || (big_cfg != 1 && big_cfg != 4)) return MC_ERR_UNSUPPORTED;
+        const int rc5 = gemm5_dispatch(p, mode, big_cfg == 1 ? 0 : 4, rowsA, s);
+        g_last_kernel = big_cfg == 1 ? 51 : 54;
+        return rc5 == MC_OK ? (big_cfg == 1 ? 64 : 32) : rc5;
+    }
     static const int two_wg_env = MC_ENV_INT("MC_GEMM5_2WG", MC_GEMM5_2WG_DEFAULT);
     const int two_wg = two_wg_env >= 0 ? two_wg_env : (share == 0 ? 4 : 0);
     if (big_cfg == 1 && automatic && !no_g5 && two_wg && mode == DENSE && N % 160 == 0) {
@@ -148,10 +163,10 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
     return gemm2_dispatch(p, mode, small_tile, deep, rowsA, s);
 }
 
-extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
-                           const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
-                           int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
-                           int rows_per_batch, float alpha, int flags, void* stream) {
+static int gemm_entry(const void* A, const void* A2, const void* W, void* C, const void* R,
+                      const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
+                      int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
+                      int rows_per_batch, float alpha, int flags, void* stream, float* gn_partial, int gn_hw) {
     const int tile = flags & 0xFF;        // 0 = auto, 64, 128
     const int epi = (flags & 0x200) ? 1 : 0;   // fused GEGLU epilogue (weights row-interleaved h/gate)
     const int deep = (flags & 0x400) ? 1 : 0;  // 3-stage LDS ring of the small-tile kernels
@@ -188,6 +203,8 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
 #endif
     p.splits = 1;
     p.s2_pad = (flags & 0x800) ? 0 : 1;
+    p.gn_partial = gn_partial;
+    p.gn_hw = gn_hw;
     hipStream_t s = (hipStream_t)stream;
 
     // 2 GiB descriptor limit: cut the problem into row ranges (whole frames for the conv modes).  With a per-batch bias
@@ -207,6 +224,7 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
     const size_t bytes_per_unit = std::max(in_rows_per_unit * per_in_row, out_rows_per_unit * per_out_row);
     size_t units_per_call = units;
     if (units * bytes_per_unit > lim) {
+        if (gn_partial) return MC_ERR_UNSUPPORTED;   // (statistics are laid out for ONE launch)
         units_per_call = lim / bytes_per_unit;
         if (units_per_call == 0) return MC_ERR_UNSUPPORTED;
         if (bias && (size_t)rows_per_batch < (size_t)M) {   // keep every range inside / aligned with the bias batches
@@ -243,9 +261,37 @@ extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C
             q.rows_per_batch = q.M;
         }
         int rc = gemm_one(q, mode, tile, deep, big_cfg, nsplit, share, s);
-        if (rc != MC_OK) return rc;
+        if (rc != MC_OK) return rc;      // (with gn_partial: one launch, and its chunk height > 0 is the result)
     }
     return MC_OK;
+}
+
+extern "C" int mc_gemm_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
+                           const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
+                           int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
+                           int rows_per_batch, float alpha, int flags, void* stream) {
+    return gemm_entry(A, A2, W, C, R, bias, M, N, K, lda, lda2, ldc, ldr, c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, alpha,
+                      flags, stream, nullptr, 0);
+}
+
+// mc_gemm_f16 that ALSO leaves the GroupNorm(32) partial sums of its output (round 6): the statistics pass of the norm that reads
+// C next - resnet.py:197 (norm2 after conv1), the next block's norm1 / Transformer3DModel.norm / the motion module's norm after
+// conv2 + shortcut (resnet.py:203-213, attention.py:105, motion_module.py:145) - is written by the producing kernel's epilogue.
+//   gn_partial: float[(M / gn_hw) * (gn_hw / 32) * 64] (mc_workspace_bytes_gemm_gnstats), gn_hw: tokens per frame.
+// Returns the CHUNK HEIGHT the sums were written with (64 or 32 rows: pass gn_hw / that to mc_groupnorm_fwd_partial_f16), or
+// MC_ERR_UNSUPPORTED (-2) with NOTHING launched when the library's own choice for this problem is not a one-pass gemm5 kernel,
+// N / 32 is not 10 / 20 / 40 channels per group, or a 64-row (32-row) wave tile would straddle frames: call mc_gemm_f16 and
+// mc_groupnorm_fwd_f16 instead.
+extern "C" long mc_workspace_bytes_gemm_gnstats(int frames, int hw) {
+    return (frames <= 0 || hw <= 0 || hw % 32) ? -1 : (long)sizeof(float) * frames * (hw / 32) * 64;
+}
+extern "C" int mc_gemm_gnstats_f16(const void* A, const void* A2, const void* W, void* C, const void* R,
+                                   const float* bias, int M, int N, int K, int lda, int lda2, int ldc, int ldr,
+                                   int c1, int ctot, int mode, int Hs, int Ws, int Ho, int Wo,
+                                   int rows_per_batch, float alpha, int flags, float* gn_partial, int gn_hw, void* stream) {
+    if (!gn_partial || gn_hw <= 0 || (flags & 0x200)) return MC_ERR_UNSUPPORTED;
+    return gemm_entry(A, A2, W, C, R, bias, M, N, K, lda, lda2, ldc, ldr, c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, alpha,
+                      flags, stream, gn_partial, gn_hw);
 }
 
 // ---- persistent tile loop (round 6, gemm6.hip) ---------------------------------------------------------------------------
@@ -320,13 +366,16 @@ extern "C" int mc_norm_gemm_f16(const void* A, const void* W, void* C, const flo
     hipStream_t s = (hipStream_t)stream;
     if (kind == 2) {
         if (hw <= 0 || M % hw || hw % 256 || !partial || !stats) return MC_ERR_UNSUPPORTED;
+        // flags bits 16-23 (round 6): `partial` already HOLDS the per-chunk sums, written with that many chunks per frame by the
+        // kernel that produced A (mc_gemm_gnstats_f16): no statistics pass here
+        const int ready_chunks = (flags >> 16) & 0xFF;
         np.partial = partial;
-        np.nchunk = mc_gn_nchunk(hw);
+        np.nchunk = ready_chunks ? ready_chunks : mc_gn_nchunk(hw);
         np.gn_n = (float)hw * (K / 32);
         // nothing is launched for a problem the fused kernel will refuse (2 GiB descriptor limits, alignment): the caller's
         // fallback (GroupNorm, then GEMM) then runs the partial pass exactly once
         if (gemm4_check(p, &np) != MC_OK) return MC_ERR_UNSUPPORTED;
-        int rc = gn_partial_launch(A, lda, K, M / hw, hw, partial, s);
+        int rc = ready_chunks ? MC_OK : gn_partial_launch(A, lda, K, M / hw, hw, partial, s);
         if (rc != MC_OK) return rc;
     }
     g_last_kernel = 4;

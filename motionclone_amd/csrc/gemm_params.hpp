@@ -29,6 +29,9 @@ struct GemmParams {
     float* ws;  // split-K: fp32 partial sums [splits][M][N] (then C/R/bias are applied by the reduce kernel); else null
     int splits; // number of K ranges (grid.y); 1 without split-K
     int dbg;    // timing experiments only (MC_GEMM_DEBUG): 1 = no global stores, 2 = no k-loop, 4 = no epilogue
+    // mc_gemm_gnstats_f16 (gemm5 / gemm6 one-pass epilogues): GroupNorm partial sums of the OUTPUT, see gemm5_tile.hpp tile_epilogue
+    float* gn_partial = nullptr;
+    int gn_hw = 0;
 };
 
 // normalisation applied to the rows of A inside the K = 320 streaming kernel (gemm4.hip, mc_norm_gemm_f16)

@@ -131,15 +131,17 @@ __global__ void gn_finalize_kernel(const float* partial, float* stats, int frame
 // y = (x - mean) * rstd * gamma + beta, optional SiLU; out is [tokens][ctot] (ld = ldo).
 // grid (nchunk, frames), block = VC * R threads: a thread owns one 8-channel vector column for the whole chunk, so
 // the per-channel scale / shift (rstd*gamma, beta - mean*rstd*gamma) are computed once and live in registers.
-// partial != nullptr: the statistics come from the per-chunk partials (gn_block_stats) and `stats` is an OUTPUT.
+// partial != nullptr: the statistics come from the per-chunk partials (gn_block_stats) and `stats` is an OUTPUT; `pchunks` = the
+// chunks per frame those partials were written with (gn_partial_kernel: nchunk; a producing GEMM's epilogue: hw / 64 or hw / 32).
 __global__ void gn_apply_kernel(GnSrc s, float* stats, const float* gamma, const float* beta,
-                                half_t* out, int ldo, int R, int nchunk, int silu, const float* partial, float n, float eps) {
+                                half_t* out, int ldo, int R, int nchunk, int silu, const float* partial, float n, float eps,
+                                int pchunks) {
     __shared__ float bst[64];
     const int VC = s.ctot / 8;
     const int t = threadIdx.x;
     const int col = t % VC, r = t / VC;
     const int frame = blockIdx.y, chunk = blockIdx.x;
-    if (partial) gn_block_stats(partial, frame, nchunk, n, eps, 0, bst, stats, chunk == 0);
+    if (partial) gn_block_stats(partial, frame, pchunks, n, eps, 0, bst, stats, chunk == 0);
     if (r >= R) return;
     const int per = (s.hw + nchunk - 1) / nchunk;
     const int t0 = chunk * per;
@@ -579,7 +581,7 @@ extern "C" int mc_groupnorm_apply_f16(const void* a, const void* b, int lda, int
     if (!gn_geometry(ctot, &R, &threads)) return MC_ERR_UNSUPPORTED;
     int nchunk = mc_gn_nchunk(hw);
     MC_LAUNCH(gn_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, const_cast<float*>(stats), gamma,
-              beta, (half_t*)out, ldo, R, nchunk, silu, (const float*)nullptr, 0.f, 0.f);
+              beta, (half_t*)out, ldo, R, nchunk, silu, (const float*)nullptr, 0.f, 0.f, 0);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 
@@ -599,7 +601,24 @@ extern "C" int mc_groupnorm_fwd_f16(const void* a, const void* b, int lda, int l
     size_t smem = (size_t)2 * R * ctot * sizeof(float);
     MC_LAUNCH(gn_partial_kernel, dim3(nchunk, frames), dim3(threads), smem, (hipStream_t)stream, s, R, nchunk, partial);
     MC_LAUNCH(gn_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, stats, gamma, beta,
-              (half_t*)out, ldo, R, nchunk, silu, (const float*)partial, (float)hw * s.cpg, eps);
+              (half_t*)out, ldo, R, nchunk, silu, (const float*)partial, (float)hw * s.cpg, eps, nchunk);
+    return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
+}
+
+// mc_groupnorm_fwd_f16 WITHOUT its statistics pass (round 6): the per-chunk partial sums were left by the kernel that produced
+// `a` (mc_gemm_gnstats_f16: `pchunks` = hw / the chunk height it returned).  ONE launch; single source.  The chunk sums are added
+// in chunk order by every workgroup's prologue (gn_block_stats), as for mc_groupnorm_fwd_f16.
+extern "C" int mc_groupnorm_fwd_partial_f16(const void* a, int lda, int ctot, int frames, int hw, float eps,
+                                            const float* partial, int pchunks, float* stats, const float* gamma,
+                                            const float* beta, void* out, int ldo, int silu, void* stream) {
+    GnSrc s;
+    if (!make_src(&s, a, nullptr, lda, 0, ctot, ctot, hw) || frames <= 0 || hw <= 0 || ldo % 8) return MC_ERR_SHAPE;
+    if (!partial || pchunks <= 0 || pchunks > 256) return MC_ERR_SHAPE;
+    int R, threads;
+    if (!gn_geometry(ctot, &R, &threads) || threads < 64) return MC_ERR_UNSUPPORTED;
+    int nchunk = mc_gn_nchunk(hw);
+    MC_LAUNCH(gn_apply_kernel, dim3(nchunk, frames), dim3(threads), 0, (hipStream_t)stream, s, stats, gamma, beta,
+              (half_t*)out, ldo, R, nchunk, silu, partial, (float)hw * s.cpg, eps, pchunks);
     return MC_LAST_ERROR() ? MC_ERR_LAUNCH : MC_OK;
 }
 

@@ -306,10 +306,11 @@ class UNet3DEngine:
         (mc_norm_gemm_f16: the normalised tensor never reaches HBM), elsewhere GroupNorm then GEMM."""
         w = self.w
         gN, bN, W, bias = w.vec(gname), w.vec(bname), w.lin(wname), w.vec(wbias).unsqueeze(0)
-        r = ops.norm_gemm(x, W, 2, gN, bN, bias=bias, hw=hw, eps=1e-6)
+        gp = ops.gnp_of(x, hw)       # statistics left by the epilogue of the GEMM that produced x (round 6), or None
+        r = ops.norm_gemm(x, W, 2, gN, bN, bias=bias, hw=hw, eps=1e-6, gnp=gp)
         if r is not None:
             return r
-        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6)
+        hn, st = ops.gn_fwd(x, None, gN, bN, False, fr, hw, 1e-6, gnp=gp)
         return ops.gemm(hn, W, bias=bias), st
 
     def _ln_gemm(self, h, gname, bname, W, tape, bias=None, pe=None, hw=0):
@@ -377,11 +378,12 @@ class UNet3DEngine:
             tb, rpb = tb.contiguous(), geo.F * hw
         g1w, b1 = w.vec(p + "norm1.weight"), w.vec(p + "norm1.bias")
         g2, b2 = w.vec(p + "norm2.weight"), w.vec(p + "norm2.bias")
-        h1, st1 = ops.gn_fwd(x, x2, g1w, b1, True, fr, hw, eps)
-        h2 = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=rpb, mode=CONV_S1,
-                      geom=(H, W, H, W), m_out=geo.T)
+        h1, st1 = ops.gn_fwd(x, x2, g1w, b1, True, fr, hw, eps, gnp=ops.gnp_of(x, hw) if x2 is None else None)
+        # (round 6) norm2's statistics come from conv1's epilogue where the library runs a one-pass ring kernel (gp; else None)
+        h2, gp = ops.gemm(h1, w.conv(p + "conv1.weight"), bias=tb, rows_per_batch=rpb, mode=CONV_S1,
+                          geom=(H, W, H, W), m_out=geo.T, gn_hw=hw)
         del h1
-        h3, st2 = ops.gn_fwd(h2, None, g2, b2, True, fr, hw, eps)
+        h3, st2 = ops.gn_fwd(h2, None, g2, b2, True, fr, hw, eps, gnp=gp)
         has_sc = (p + "conv_shortcut.weight") in w.sd
         if has_sc:
             sc = ops.gemm(x, w.lin(p + "conv_shortcut.weight"), a2=x2,
@@ -389,8 +391,11 @@ class UNet3DEngine:
         else:
             assert x2 is None
             sc = x
-        out = ops.gemm(h3, w.conv(p + "conv2.weight"), bias=w.vec(p + "conv2.bias").unsqueeze(0), residual=sc,
-                       mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T)
+        # (the block's output is normalised next by Transformer3DModel.norm / the motion module's norm / the next block's norm1:
+        # its statistics ride on the tensor, ops.gnp_of)
+        out, gpo = ops.gemm(h3, w.conv(p + "conv2.weight"), bias=w.vec(p + "conv2.bias").unsqueeze(0), residual=sc,
+                            mode=CONV_S1, geom=(H, W, H, W), m_out=geo.T, gn_hw=hw)
+        ops.tag_gnp(out, gpo, hw)
         if tape is not None:
             g1, cut = self._bslice(geo, tape.grad_batch)
             bx, bx2, bst1, bh2, bst2 = cut(x), cut(x2), cut(st1), cut(h2), cut(st2)

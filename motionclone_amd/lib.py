@@ -26,6 +26,8 @@ SIGNATURES = {
     "mc_workspace_bytes_attn_bwd": [I, I, I],
     "mc_workspace_bytes_tattn_loss": [I, I, I],
     "mc_gemm_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P],
+    "mc_workspace_bytes_gemm_gnstats": [I, I],
+    "mc_gemm_gnstats_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, I, I, I, I, I, I, F, I, P, I, P],
     "mc_workspace_bytes_gemm_tileloop": [I],
     "mc_gemm_tileloop_f16": [P, P, P, P, P, P, I, I, I, I, I, I, I, I, I, F, I, P, ctypes.c_size_t, P, ctypes.c_size_t, P],
     "mc_norm_gemm_f16": [P, P, P, P, I, I, I, I, I, I, P, P, P, I, I, F, P, P, I, P],
@@ -45,6 +47,7 @@ SIGNATURES = {
     "mc_groupnorm_stats_f16": [P, P, I, I, I, I, I, I, F, P, P, P],
     "mc_groupnorm_apply_f16": [P, P, I, I, I, I, I, I, P, P, P, P, I, I, P],
     "mc_groupnorm_fwd_f16": [P, P, I, I, I, I, I, I, F, P, P, P, P, P, I, I, P],
+    "mc_groupnorm_fwd_partial_f16": [P, I, I, I, I, F, P, I, P, P, P, P, I, I, P],
     "mc_groupnorm_bwd_f16": [P, P, I, I, I, I, I, I, P, I, P, P, P, I, P, P, P, I, I, P],
     "mc_layernorm_fwd_f16": [P, I, P, I, P, P, P, I, I, P, I, I, F, P],
     "mc_layernorm_bwd_f16": [P, I, P, I, P, P, P, I, P, I, I, I, P],
@@ -156,6 +159,23 @@ def try_call(name, *args):
     if rc != 0:
         raise RuntimeError("%s failed: %s (rc=%d)" % (name, ERRORS.get(rc, "unknown"), rc))
     return True
+
+
+def call_count(name, *args):
+    """entry points that answer with a non-negative count on success (mc_gemm_gnstats_f16: the chunk height): the count, or
+    False for MC_ERR_UNSUPPORTED (-2: nothing was launched, the caller issues the general sequence); other errors raise"""
+    if _lib is None or _FN.get("__lib__") is not _lib:
+        _FN.clear()
+        _FN["__lib__"] = load()
+    fn = _FN.get(name)
+    if fn is None:
+        fn = _FN[name] = getattr(_lib, name)
+    rc = fn(*args)
+    if rc == -2:
+        return False
+    if rc < 0:
+        raise RuntimeError("%s failed: %s (rc=%d)" % (name, ERRORS.get(rc, "unknown"), rc))
+    return rc
 
 
 def call(name, *args):

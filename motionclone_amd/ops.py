@@ -198,8 +198,12 @@ def gemm_tileloop(a, w, *, a2=None, bias=None, residual=None, out=None, alpha=1.
 
 def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=None, alpha=1.0,
          rows_per_batch=0, tile=0, m_out=None, geglu=False, deep=False, cfg=0, splits=None,
-         pad_front=True, nsplit=0, g3_splitk=False, tileloop=None):
+         pad_front=True, nsplit=0, g3_splitk=False, tileloop=None, gn_hw=0):
     """out[M,N] = alpha * gather(a, a2) . w[N,K]^T + bias + residual.
+
+    gn_hw > 0 (round 6): the caller will GroupNorm `out` next, in frames of gn_hw tokens -> returns (out, gnp) where gnp =
+    (partial sums written by the producing kernel's epilogue, chunks per frame) for `gn_fwd(..., gnp=gnp)`, or None when the
+    library's choice for this problem leaves no statistics (then gn_fwd runs its own statistics pass).
 
     geom = (Hs, Ws, Ho, Wo) for the conv modes; m_out = number of output tokens for conv modes.
     geglu=True: w rows interleaved (h_j, gate_j) (see `interleave_geglu`), out gets N/2 columns h*gelu(gate).
@@ -229,7 +233,7 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
             and (tileloop or _tileloop_wanted(M, N, K, share)):
         if gemm_tileloop(a, w, a2=a2, bias=bias, residual=residual, out=out, alpha=alpha, rows_per_batch=rows_per_batch,
                          geglu=geglu) is not None:
-            return out
+            return (out, None) if gn_hw else out
     flags = tile | (0x200 if geglu else 0) | (0x400 if deep else 0) | (cfg << 12) \
         | (0 if pad_front else 0x800) | (nsplit << 16) | (share << 20) | (0x1000000 if g3_splitk else 0)
     if bias is not None:
@@ -251,11 +255,31 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
         lib.call("mc_gemm_splitk_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
                  _ld(a2), _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha),
                  flags, _p(ws), splits, _stream(a))
-        return out
+        return (out, None) if gn_hw else out
+    if gn_hw and GN_FROM_EPILOGUE and not (tile or deep or geglu) and cfg in (0, 11, 15) and M % gn_hw == 0 and gn_hw % 32 == 0 and N in (320, 640, 1280):
+        part = torch.empty(lib.workspace_bytes("gemm_gnstats", M // gn_hw, gn_hw) // 4, dtype=torch.float32, device=a.device)
+        rows = lib.call_count("mc_gemm_gnstats_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
+                              _ld(a2), _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha),
+                              flags, _p(part), gn_hw, _stream(a))
+        if rows:
+            return out, (part, gn_hw // rows)
     lib.call("mc_gemm_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a), _ld(a2),
              _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha), flags,
              _stream(a))
-    return out
+    return (out, None) if gn_hw else out
+
+
+def gnp_of(x, hw):
+    """the GroupNorm partial sums the producing GEMM's epilogue left for tensor `x` (attached by `gemm(..., gn_hw=hw)`'s caller
+    with `tag_gnp`), or None.  Views / slices / concatenations are new tensor objects and carry none."""
+    t = getattr(x, "_mc_gnp", None)
+    return t[0] if t is not None and t[1] == hw else None
+
+
+def tag_gnp(x, gnp, hw):
+    if gnp is not None:
+        x._mc_gnp = (gnp, hw)
+    return x
 
 
 def pack_conv_k(w_taps):
@@ -292,15 +316,20 @@ def gn_apply(x, x2, stats, gamma, beta, silu, frames, hw, out=None):
     return out
 
 
-def gn_fwd(x, x2, gamma, beta, silu, frames, hw, eps, out=None):
+def gn_fwd(x, x2, gamma, beta, silu, frames, hw, eps, out=None, gnp=None):
     """GroupNorm(32) (+ SiLU) of [frames * hw, c1 (+ c2)] tokens -> (out, stats); stats = (mean, rstd) per (frame, group) for
-    the backward.  gn_stats + gn_apply without the finalize launch (mc_groupnorm_fwd_f16)."""
+    the backward.  gn_stats + gn_apply without the finalize launch (mc_groupnorm_fwd_f16).
+    gnp = (partial, chunks per frame) from `gemm(..., gn_hw=hw)` that produced x: ONE launch, no statistics pass."""
     c1 = x.shape[1]
     ctot = c1 + (x2.shape[1] if x2 is not None else 0)
-    partial = workspace("groupnorm", x, frames, hw)
     stats = empty((frames, 32, 2), x, torch.float32)
     if out is None:
         out = empty((frames * hw, ctot), x)
+    if gnp is not None and x2 is None:
+        lib.call("mc_groupnorm_fwd_partial_f16", _p(x), _ld(x), ctot, frames, hw, float(eps), _p(gnp[0]), gnp[1], _p(stats),
+                 _p(_f32(gamma)), _p(_f32(beta)), _p(out), _ld(out), int(silu), _stream(x))
+        return out, stats
+    partial = workspace("groupnorm", x, frames, hw)
     lib.call("mc_groupnorm_fwd_f16", _p(x), _p(x2), _ld(x), _ld(x2), c1, ctot, frames, hw, float(eps), _p(partial),
              _p(stats), _p(_f32(gamma)), _p(_f32(beta)), _p(out), _ld(out), int(silu), _stream(x))
     return out, stats
@@ -348,10 +377,12 @@ def layernorm_bwd(dy, x, stats, gamma, add=None, out=None):
 # (GroupNorm + proj_in) at M = 65536, 25.2 vs 33.3 / 34.9 vs 47.9 at M = 32768 (profiles/r04_norm_gemm_microbench.jsonl);
 # M = 65536 is what the shared prefix of the CFG batch runs at config 2 (engine.forward: dup), M = 32768 config 1's B = 2.
 NORM_GEMM_MIN_ROWS = 32768
+# GroupNorm statistics from the producing GEMM's epilogue (mc_gemm_gnstats_f16); False = always the statistics pass (A/B)
+GN_FROM_EPILOGUE = True
 
 
 def norm_gemm(x, w, kind, gamma, beta, *, bias=None, pe=None, hw=0, eps=1e-5, save_stats=True, geglu=False, out=None,
-              stats=None, force=False):
+              stats=None, force=False, gnp=None):
     """LayerNorm (kind 1, + temporal position table `pe` [F, C]) or GroupNorm(32) without activation (kind 2, frames of `hw`
     tokens) of the rows of x [M, 320], followed by the Linear w [N, 320] (+ bias [1, N]; geglu: fused GEGLU epilogue) - ONE
     launch, the normalised rows never reach HBM (mc_norm_gemm_f16).  -> (out, stats), stats as layernorm_fwd / gn_fwd return
@@ -368,7 +399,8 @@ def norm_gemm(x, w, kind, gamma, beta, *, bias=None, pe=None, hw=0, eps=1e-5, sa
             return None
         frames = M // hw
         stats = empty((frames, 32, 2), x, torch.float32)
-        partial = workspace("groupnorm", x, frames, hw)
+        # gnp (round 6): the sums left by the epilogue of the GEMM that produced x, (partial, chunks per frame): no statistics pass
+        partial = gnp[0] if gnp is not None and gnp[1] <= 255 else workspace("groupnorm", x, frames, hw)
     else:
         if pe is not None and (hw <= 0 or hw % 256 or M % hw):
             return None
@@ -386,7 +418,8 @@ def norm_gemm(x, w, kind, gamma, beta, *, bias=None, pe=None, hw=0, eps=1e-5, sa
     ok = lib.try_call("mc_norm_gemm_f16", _p(x), _p(w), _p(out), _p(bias), M, N, K, _ld(x), _ld(out), kind,
                       _p(_f32(gamma)), _p(_f32(beta)), _p(_f32(pe)) if kind == 1 else None, hw,
                       pe.shape[0] if (kind == 1 and pe is not None) else 0, float(eps), _p(stats), _p(partial),
-                      0x200 if geglu else 0, _stream(x))
+                      (0x200 if geglu else 0) | ((gnp[1] << 16) if (kind == 2 and gnp is not None and gnp[1] <= 255) else 0),
+                      _stream(x))
     return (out, stats) if ok else None
 
 

@@ -125,6 +125,64 @@ def test_gemm5_ring_kernel(backend, var):
         close(out, a.float() @ w.float().t() + bias.repeat_interleave(150, 0), 2e-2, 5e-3, "per-batch bias, library's choice")
 
 
+@pytest.mark.parametrize("mode,N,hw,cfg,res", [("dense", 320, 64, 11, True), ("dense", 640, 128, 11, False), ("conv", 320, 64, 11, True),
+                                              ("dense", 1280, 64, 15, True), ("conv", 640, 96, 15, False), ("dense", 320, 256, 0, True)])
+def test_gemm_leaves_groupnorm_statistics_of_its_output(backend, mode, N, hw, cfg, res):
+    """mc_gemm_gnstats_f16 (round 6): the one-pass ring kernels' epilogue writes the GroupNorm(32) partial sums of the ROUNDED
+    output per (frame, chunk of 64 / 32 rows, group); mc_groupnorm_fwd_partial_f16 consumes them.  Output bit-identical to
+    mc_gemm_f16; normalised tensor and (mean, rstd) equal to the statistics-pass form to fp32 summation order (same bound as
+    test_groupnorm_fwd_bwd's two forms); refused with nothing launched where a wave tile would straddle frames (hw = 96 with
+    64-row chunks) or the channel count has no whole groups per 160 columns."""
+    dev = backend
+    frames = 3 if not big(dev) else 24
+    if cfg == 0 and not big(dev):
+        pytest.skip("the library's own choice takes the ring kernels at GPU sizes only")
+    if big(dev) and cfg == 0:
+        frames, hw = 32, 1024
+    M = frames * hw
+    bias = torch.randn(frames, N, generator=torch.Generator().manual_seed(3)).to(dev) if hw % 256 == 0 or cfg == 15 and hw % 128 == 0 \
+        else torch.randn(1, N, generator=torch.Generator().manual_seed(3)).to(dev)
+    rpb = hw if bias.shape[0] > 1 else 0
+    R = rnd((M, N), dev, 4) if res else None
+    if mode == "dense":
+        K = 128 if not big(dev) else 640
+        a, w = rnd((M, K), dev, 1), rnd((N, K), dev, 2, 0.1)
+        kw = dict()
+    else:
+        Cin = 64 if not big(dev) else 320
+        H, W = {64: (8, 8), 96: (8, 12), 128: (8, 16), 256: (16, 16), 1024: (32, 32)}[hw]
+        a = rnd((M, Cin), dev, 1)
+        w = _conv_w_pack(rnd((N, Cin, 3, 3), dev, 2, 0.05))
+        kw = dict(mode=ops.CONV_S1, geom=(H, W, H, W), m_out=M)
+    plain = ops.gemm(a, w, bias=bias, residual=R, rows_per_batch=rpb, cfg=cfg, tileloop=False, **kw)
+    out, gnp = ops.gemm(a, w, bias=bias, residual=R, rows_per_batch=rpb, cfg=cfg, tileloop=False, gn_hw=hw, **kw)
+    rows = 64 if cfg == 11 else 32 if cfg == 15 else None      # (cfg 0: whichever of the two tile heights the library takes)
+    if rows is None:
+        assert gnp is not None and gnp[1] in (hw // 64, hw // 32)
+        rows = hw // gnp[1]
+    if hw % rows:
+        assert gnp is None, "a wave tile that straddles two frames must be refused"
+        assert torch.equal(out, plain)
+        return
+    assert gnp is not None and gnp[1] == hw // rows
+    assert torch.equal(out, plain), "the statistics epilogue changed the GEMM's output"
+    gamma = (1 + 0.1 * torch.randn(N, generator=torch.Generator().manual_seed(5))).to(dev)
+    beta = (0.1 * torch.randn(N, generator=torch.Generator().manual_seed(6))).to(dev)
+    y0, st0 = ops.gn_fwd(out, None, gamma, beta, True, frames, hw, 1e-5)
+    y1, st1 = ops.gn_fwd(out, None, gamma, beta, True, frames, hw, 1e-5, gnp=gnp)
+    close(st1, st0, 1e-5, 1e-5, "statistics from the epilogue vs the statistics pass")
+    close(y1, y0, 2e-3, 2e-3, "normalised output")
+    assert (y1 != y0).float().mean().item() < 0.02
+    xr = out.float().reshape(frames, hw, N).permute(0, 2, 1)
+    ref = Fn.silu(Fn.group_norm(xr, 32, gamma, beta, 1e-5)).permute(0, 2, 1).reshape(M, N)
+    close(y1, ref, 1e-2, 5e-3, "GroupNorm + SiLU from epilogue statistics vs fp32 torch")
+    # the sums themselves: every (frame, chunk, group) slot against fp64 sums of the stored fp16 values
+    part = gnp[0][:frames * gnp[1] * 64].reshape(frames, gnp[1], 32, 2).double().cpu()
+    xo = out.double().cpu().reshape(frames, gnp[1], rows, 32, N // 32)
+    want = torch.stack([xo.sum((2, 4)), (xo * xo).sum((2, 4))], -1)
+    assert torch.allclose(part, want, rtol=1e-5, atol=1e-3), (part - want).abs().max().item()
+
+
 @pytest.mark.parametrize("dynamic", [False, True])
 def test_gemm6_persistent_tile_loop_equals_gemm5_bit_for_bit(backend, dynamic):
     """gemm6.hip (mc_gemm_tileloop_f16: one workgroup per CU walks the 256x320 tiles, the operand ring runs through tile
