@@ -215,7 +215,8 @@ def reference_gpu_baseline(dev, size=512, sched=(30, 18, 0.4)):
 
 
 TIMED_DURATIONS_FILE = os.path.join("profiles", "kernel_durations_timed.json")
-_G5_TILES = {(256, 320): "gemm5<256x320>", (128, 320): "gemm5<128x320>", (256, 160): "gemm5<256x160 x2 per CU>"}
+_G5_TILES = {(256, 320): "gemm5<256x320>", (128, 320): "gemm5<128x320>", (256, 160): "gemm5<256x160 x2 per CU>",
+             (256, 256): "gemm5<256x256, 4 waves>"}
 _MODE_NAMES = ["DENSE", "CONV_S1", "CONV_S2", "CONV_UP", "TCONV_S2"]
 
 
@@ -229,6 +230,9 @@ def family_of_traced_kernel(name):
         mode, bm, bn = int(m.group(1)), int(m.group(4)), int(m.group(5))
         base = _G5_TILES.get((bm, bn))
         return "%s %s" % (base, _MODE_NAMES[mode]) if base and mode < len(_MODE_NAMES) else None
+    m = re.search(r"gemm6_kernel<(\d+), (\d+), (\d+), (\d+)>", name)      # <EPI, RES, VAR, stream-K>
+    if m:
+        return "gemm6<256x320 tile loop%s> DENSE" % (", stream-K" if int(m.group(4)) else "")
     m = re.search(r"gemm4_kernel<(\d+), (\w+), (\d+)>", name)
     if m:
         return "gemm4<K=320 streaming> " + {0: "DENSE", 1: "LayerNorm + DENSE", 2: "GroupNorm + DENSE"}.get(int(m.group(3)), "?")
@@ -244,7 +248,7 @@ def loaded_lib_stamp():
         return None
 
 
-def timed_roofline(roof_all, prof):
+def timed_roofline(roof_all, prof, lanes=3, batch=1):
     """The dominant GEMM family IN THE TIMED REGIME (hipGraph replay, several videos in flight): HIP events cannot bracket
     launches inside a graph replay, so the per-launch DURATION comes from a rocprofv3 --kernel-trace --stats run of this same
     command (profiles/kernel_durations_timed.json, written by tools/kernel_stats_md.py from the round's profile run; its
@@ -256,7 +260,10 @@ def timed_roofline(roof_all, prof):
         return None
     # a trace is only this run's kernels if it was taken from THIS library on THIS device: tools/kernel_stats_md.py records the
     # library's source stamp (build.py's sha1 of sources + flags, next to the .so) and the device name; anything else is refused
-    stamp, devname = loaded_lib_stamp(), torch.cuda.get_device_name(0)
+    stamp, devname = loaded_lib_stamp(), (torch.cuda.get_device_name(0) if torch.cuda.is_available() else None)
+    if (prof.get("lanes", 3), prof.get("batch", 1)) != (lanes, batch):
+        return dict(achieved=None, frac=None, source=TIMED_DURATIONS_FILE, code=prof.get("code"),
+                    reason="the trace was taken with %s lanes x %s videos, this run has %d x %d" % (prof.get("lanes", 3), prof.get("batch", 1), lanes, batch))
     if prof.get("lib_stamp") is None or prof.get("lib_stamp") != stamp or prof.get("device") != devname:
         return dict(achieved=None, frac=None, source=TIMED_DURATIONS_FILE, code=prof.get("code"),
                     reason="stale trace: recorded for library stamp %s on %s, this run loaded %s on %s - re-run the profile (tools/gpu_profile.sh)"
@@ -285,6 +292,26 @@ def timed_roofline(roof_all, prof):
         if best is None or row["share_of_kernel_time"] > best["share_of_kernel_time"]:
             best = row
     return best
+
+
+def auto_packing(steps, frames, size, sparsectrl):
+    """(lanes, videos batched per lane) when --inflight / --batch are not given.  Independent videos are the unit of parallelism
+    (SURVEY.md 8e); a GPU holds several: `lanes` launch sequences on their own streams (kernel tails and the small 16x16 / 8x8-level
+    launches of one are filled by the others) x `batch` videos that go through ONE launch sequence ([V, ...] latents: the same
+    kernels on V times the rows - fewer, larger launches, the small levels fill the chip).  Measured at config 2 on one MI355X
+    (profiles/r06_packing.txt, videos/min, GiB reserved): 3 x 1 36.8 (46), 3 x 2 38.0 (83), 2 x 3 37.7 (83), 2 x 4 38.3 (106),
+    2 x 5 38.8 (131), 2 x 6 39.0 (157), 3 x 4 39.1 (156), 1 x 8 37.8 (110).  The choice: two lanes, up to five videos each
+    (131 GiB of the 288), with lanes x batch dividing --steps so that every round is a full one; other shapes keep round 5's
+    three lanes x one video (config 5's 32 f x 768^2 holds 2 lanes; SparseCtrl is not batched)."""
+    if sparsectrl or (frames, size) != (16, 512):
+        return (2 if frames * size * size > 16 * 512 * 512 else 3), 1
+    for vb in (5, 4, 3):
+        if steps % (2 * vb) == 0:
+            return 2, vb
+    for nf, vb in ((3, 2), (2, 2)):
+        if steps % (nf * vb) == 0:
+            return nf, vb
+    return 3, 1
 
 
 def spawn_ranks(n):
@@ -371,12 +398,12 @@ def compact_line(res, detail_path, limit=4000):
 
 
 def write_detail(res):
-    """full record -> profiles/r05_bench_detail.json (and gpurun_out/, which is what travels back from a GPU box)"""
-    rel = os.path.join("profiles", "r05_bench_detail.json")
+    """full record -> profiles/r06_bench_detail.json (and gpurun_out/, which is what travels back from a GPU box)"""
+    rel = os.path.join("profiles", "r06_bench_detail.json")
     for d in ("profiles", "gpurun_out"):
         try:
             os.makedirs(os.path.join(ROOT, d), exist_ok=True)
-            with open(os.path.join(ROOT, d, "r05_bench_detail.json"), "w") as f:
+            with open(os.path.join(ROOT, d, "r06_bench_detail.json"), "w") as f:
                 json.dump(res, f, indent=1)
         except OSError:
             pass
@@ -410,15 +437,15 @@ def main():
                     "runs that should hold the timed regime's kernels only: tools/gpu_profile_r05.sh)")
     ap.add_argument("--probe-one-lane", action="store_true", help="roofline probe video with the tile choice of ONE video in flight "
                     "(round 4's probe regime) instead of the timed region's")
-    ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r05_bench_detail.json")
+    ap.add_argument("--no-detail", action="store_true", help="do not write profiles/r06_bench_detail.json")
     ap.add_argument("--no-vae", action="store_true", help="skip the (untimed, informational) VAE decode / encode measurement")
-    ap.add_argument("--batch", type=int, default=1, help="videos batched into ONE launch sequence per lane (latents [V, ...], text "
+    ap.add_argument("--batch", type=int, default=0, help="(0 = automatic, see auto_packing) videos batched into ONE launch sequence per lane (latents [V, ...], text "
                     "[u_1 .. u_V | c_1 .. c_V]: the same kernels on V times the rows); --inflight lanes x --batch videos are in "
                     "flight together.  --steps must be a multiple of it")
     ap.add_argument("--tileloop", choices=["auto", "off", "all"], default="auto", help="A/B: the persistent tile loop (gemm6.hip) for the "
                     "dense 256x320-tile layers: auto = the library's measured policy, off = never (round 5's kernels), all = every "
                     "shape the kernel accepts")
-    ap.add_argument("--inflight", type=int, default=3, help="independent videos processed concurrently per GPU (own HIP stream, "
+    ap.add_argument("--inflight", type=int, default=0, help="(0 = automatic, see auto_packing) independent videos processed concurrently per GPU (own HIP stream, "
                     "own sampler / graphs each).  At config 2: 2 in flight +8-10 %% videos/min over one (kernel tails and the "
                     "small 16x16 / 8x8-level kernels of one video are filled by the others), 3 in flight another +2.6 %%, 4 lose; "
                     "results bit-identical to the one-at-a-time run (checked in the run: `eager.identical_to_graph_path`, "
@@ -496,6 +523,11 @@ def main():
     # sequence of one video leaves CUs idle in kernel tails and in the small 16x16 / 8x8-level kernels, which a second video
     # fills (measured +8-10 % videos/min for 2 in flight, nothing more for 3: tools/concurrency_probe.py).  Results are
     # bit-identical to the one-at-a-time run since the library is built without packed-fp32 VALU code (csrc/temporal.hip).
+    auto_nf, auto_vb = auto_packing(args.steps, args.frames, args.size, args.sparsectrl)
+    if args.batch <= 0:      # a given --inflight alone keeps round 5's one video per lane
+        args.batch = auto_vb if args.inflight <= 0 else 1
+    if args.inflight <= 0:
+        args.inflight = auto_nf if args.batch == auto_vb else 3
     VB = max(1, args.batch)
     if args.steps % VB or (args.sparsectrl and VB > 1):
         raise SystemExit("bench.py: --steps must be a multiple of --batch (and --batch 1 with --sparsectrl)")
@@ -591,7 +623,10 @@ def main():
             torch.cuda.synchronize()
         probe.enabled = True
         tp0 = time.perf_counter()
-        one_video(sme, lat, text, vid, noise, ctrl=ctrl)
+        if args.probe_one_lane:
+            one_video(sme, lat, text, vid, noise, ctrl=ctrl)
+        else:
+            eager_lane0()          # lane 0's job as the timed region runs it: its --batch videos as ONE launch sequence
         torch.cuda.synchronize()
         probe_elapsed = time.perf_counter() - tp0
         probe.enabled = False
@@ -645,10 +680,10 @@ def main():
                 "one video in flight" if args.probe_one_lane else "the timed region (%d in flight)" % NF))
         roof_timed = None
         tdf = os.path.join(ROOT, TIMED_DURATIONS_FILE)
-        if (os.path.exists(tdf) and (args.frames, args.size, N_STEPS, G_STEPS) == (16, 512, 30, 18) and use_graphs and NF == 3
-                and VB == 1 and not args.sparsectrl and not args.probe_one_lane):
+        if (os.path.exists(tdf) and (args.frames, args.size, N_STEPS, G_STEPS) == (16, 512, 30, 18) and use_graphs
+                and not args.sparsectrl and not args.probe_one_lane):
             try:
-                roof_timed = timed_roofline(roof_all, json.load(open(tdf)))
+                roof_timed = timed_roofline(roof_all, json.load(open(tdf)), NF, VB)
             except Exception as e:   # noqa: BLE001  (a stale / malformed profile must not cost the record)
                 roof_timed = {"error": "%s: %s" % (type(e).__name__, e)}
         hbm = dict(peak_allocated_gib=timed_allocated, peak_reserved_gib=timed_reserved, videos_in_flight=NF,

@@ -29,10 +29,11 @@ namespace mc {
 // in the first half of a stage, waves 4-7 in the second; measured 1-8 % slower than everybody in the first half, which is the
 // default), bit 1 = loads issued in one burst at the top of the half instead of interleaved with the MFMAs.
 template <int MODE, int EPI, int VAR, int BM, int BN = g5::BN, int NW = g5::NW, int NS = g5::NS, int RES = 0, int GNS = 0>
-__global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
+__global__ __launch_bounds__(NW * 64, (NW == 8 || BN >= 256) ? 1 : 2) void gemm5_kernel(GemmParams p, uint32_t bytesA, uint32_t bytesA2,
                                                                           uint32_t bytesW, int tilesM, int tilesN, int sm, int sn) {
-    using g5::TN; using g5::BKT; using g5::RPI; using g5::STG; using g5::lds_off32;
+    using g5::BKT; using g5::RPI; using g5::STG; using g5::lds_off32;
     using T = g5::Tile<BM, BN, NW, NS>;
+    constexpr int TN = T::TNV, WCOL = T::WCOL;
     constexpr int TM = T::TM, RA = T::RA, STAGE = T::STAGE, A_BYTES = T::A_BYTES, LA = T::LA, LB = T::LB, WB = T::WB, WX = T::WX, WXD = T::WXD;
     constexpr int WMW = T::WMW;
     MC_DYN_SMEM(smem);
@@ -184,7 +185,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void ge
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int wr = wave % WMW, wc = wave / WMW;
-    const int wm0 = wr * (32 * TM), wn0 = wc * 160;
+    const int wm0 = wr * (32 * TM), wn0 = wc * WCOL;
     const int l31 = lane & 31, lhi = lane >> 5;
 
     const int split = blockIdx.y;
@@ -321,7 +322,7 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void ge
     // The wave's 160 bias values are requested here, in front of the last ring stages (the counted waits below only get stricter).
     const bool new_epi = !p.ws;      // (gemm5_dispatch admits only problems whose tiles see ONE bias row)
     f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (new_epi && p.bias) bias4 = load_bias4(p.bias, p.rows_per_batch >= p.M ? 0 : m0 / p.rows_per_batch, p.N, n0 + wn0);
+    if (new_epi && p.bias) bias4 = load_bias4<WCOL>(p.bias, p.rows_per_batch >= p.M ? 0 : m0 / p.rows_per_batch, p.N, n0 + wn0);
     // tail: nothing left to issue (the next stage's slice-0 fragments read after the last stage are stale and never used)
     for (; kt < nk; ++kt) {
         const int nbuf = nxt(buf);
@@ -333,6 +334,9 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void ge
     }
     // every wave passed the last barrier after its final LDS read and no load is in flight: the ring is free
 
+    if constexpr (TN != g5::TN) {
+        if (p.ws) return;     // (gemm5_dispatch refuses split-K for the 128-column wave tiles: the slabs / reduce pass are 160-column)
+    }
     if (p.ws) {
         // split-K: this workgroup's partial sums go to its slab in ACCUMULATOR-NATIVE order - chunk (i, j, q) of lane l at
         // float4 index ((i TM + j) 4 + q) 64 + l - so every store instruction writes 1 KiB contiguously; splitk_reduce5_kernel
@@ -352,8 +356,10 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void ge
         return;
     }
 #ifdef MC_G5_OLD_EPILOGUE   // A/B build only (build.build_old_epilogue_control): round 5's epilogue
-    g5_epilogue<EPI, TM>(p, acc, smem + wave * STG, m0 + wm0, n0 + wn0, lane);
-    return;
+    if constexpr (TN == g5::TN) {
+        g5_epilogue<EPI, TM>(p, acc, smem + wave * STG, m0 + wm0, n0 + wn0, lane);
+        return;
+    }
 #endif
     if (new_epi) {
         EpiArgs e;
@@ -367,8 +373,8 @@ __global__ __launch_bounds__(NW * 64, (NW == 8 || BN == g5::BN) ? 1 : 2) void ge
         if constexpr (GNS != 0) {
             e.gn_partial = p.gn_partial; e.gn_hw = p.gn_hw; e.gn_cpg = p.N / 32;
         }
-        tile_epilogue<EPI, RES, TM, GNS>(e, acc, img, bstrip, bias4, m0 + wm0, n0 + wn0);   // RES: with a residual (its own
-        return;                                                      // instantiation: as a run-time branch the pair spilled)
+        tile_epilogue<EPI, RES, TM, GNS, TN>(e, acc, img, bstrip, bias4, m0 + wm0, n0 + wn0);   // RES: with a residual (its own
+        return;                                                          // instantiation: as a run-time branch the pair spilled)
     }
 }
 
@@ -475,6 +481,13 @@ static int launch5_var(const GemmParams& p, uint32_t bA, uint32_t bA2, uint32_t 
         }
         return MC_ERR_UNSUPPORTED;
     }
+    if (var == 7) {      // 256 x 256 tiles, four waves, 128 x 128 wave tiles (dense, one pass)
+        if constexpr (MODE == DENSE) {
+            if (p.ws || p.gn_partial) return MC_ERR_UNSUPPORTED;
+            return p.epi == 1 ? launch5<DENSE, 1, 0, 256, 256, 4, 4>(p, bA, bA2, bW, s) : launch5<DENSE, 0, 0, 256, 256, 4, 4>(p, bA, bA2, bW, s);
+        }
+        return MC_ERR_UNSUPPORTED;
+    }
     if (var == 6) {
         if (p.ws) return MC_ERR_UNSUPPORTED;
         if (p.epi == 1) {
@@ -502,7 +515,8 @@ int gemm5_dispatch(const GemmParams& p, int mode, int var, size_t rowsA, hipStre
     if ((p.ws != nullptr) != (p.splits > 1)) return MC_ERR_UNSUPPORTED;
     if (p.ws && (p.epi == 1 || (var != 0 && var != 4))) return MC_ERR_UNSUPPORTED;
     if (var == 5 && mode != DENSE) return MC_ERR_UNSUPPORTED;
-    if (var == 1 || var == 2 || var == 3 || var > 6) return MC_ERR_UNSUPPORTED;
+    if (var == 1 || var == 2 || var == 3 || var > 7) return MC_ERR_UNSUPPORTED;
+    if (var == 7 && mode != DENSE) return MC_ERR_UNSUPPORTED;
     if ((p.N & 7) || (p.ldc & 7) || (p.R && (p.ldr & 7)) || p.K % g5::BKT) return MC_ERR_UNSUPPORTED;
     if (p.epi == 1 && (p.N & 15)) return MC_ERR_UNSUPPORTED;
     if (p.gn_partial) {

@@ -20,6 +20,11 @@ constexpr int STG = 32 * RS;             // one 32-row block of a wave's tile
 //   <256, 320, 4, 4>  (round 6) 4 waves as 2 x 2, ONE wave per SIMD with the whole 512-register file: wave tile 128 x 160 -
 //                     36 % fewer LDS fragment bytes per MFMA than the 64 x 160 wave tile (461 instead of 717), half the waves
 //                     at every barrier; 320 accumulator registers per lane
+//   <256, 256, 4, 4>  (round 6) 4 waves as 2 x 2, wave tile 128 x 128 (TM = 4, FOUR column blocks): the 256 accumulator registers
+//                     are exactly the AGPR file, every VGPR is left to fragments and addresses; 0.5 LDS fragment reads per MFMA
+//                     (0.7 for the 64 x 160 wave tile) and operands fetched once per 256 columns.  For the layers whose N is a
+//                     multiple of 256 and wide (FeedForward's first Linear, q|k|v at 1280): the geometry of the vendor
+//                     library's kernel on those shapes (profiles/r05_vendor_kernel_names.md)
 //   <256, 160, 4, 3>  (round 4) 4 waves as 4 x 1, wave tile 64 x 160, ring of 3 stages (78 KiB): TWO workgroups per CU that
 //                     run out of step - one tile's prologue / epilogue (residual read, stores) under the other's k-loop.  Same
 //                     per-wave code as the default (TM = 2), 1.44x the operand bytes per MFMA (A is fetched once per 160
@@ -27,16 +32,18 @@ constexpr int STG = 32 * RS;             // one 32-row block of a wave's tile
 template <int BM, int BN_ = BN, int NW_ = NW, int NS_ = NS>
 struct Tile {
     static constexpr int BNT = BN_, NWV = NW_, NSV = NS_, NTH = NW_ * 64;
-    static constexpr int WNW = BN_ / 160, WMW = NW_ / WNW;   // waves along N / along M
+    static constexpr int WCOL = BN_ % 160 == 0 ? 160 : 128;  // columns of a wave tile: 5 or 4 blocks of 32 (TNV)
+    static constexpr int TNV = WCOL / 32;
+    static constexpr int WNW = BN_ / WCOL, WMW = NW_ / WNW;  // waves along N / along M
     static constexpr int TM = BM / (32 * WMW);
     static constexpr int RA = BM / RPI / NW_;            // activation row groups per wave and stage
     static constexpr int WB = (BN_ / RPI) / NW_;         // weight row groups every wave moves per stage ...
     static constexpr int WX = (BN_ / RPI) % NW_;         // ... and the first WX waves one more
     static constexpr int STAGE = (BM + BN_) * ROWB;      // 36864 / 28672 / 26624
     static constexpr int A_BYTES = BM * ROWB;
-    static constexpr int LB = RA + WB, LA = RA + WB + 1; // LDS-DMA instructions per stage: waves >= WX / waves < WX
+    static constexpr int LB = RA + WB, LA = RA + WB + (WX > 0 ? 1 : 0); // LDS-DMA instructions per stage: waves >= WX / waves < WX
     static constexpr size_t SMEM = (size_t)NS_ * STAGE;
-    static_assert(BN_ % 160 == 0 && NW_ % WNW == 0 && BM % (32 * WMW) == 0 && BM % (RPI * NW_) == 0, "tile / wave grid");
+    static_assert(BN_ % WCOL == 0 && NW_ % WNW == 0 && BM % (32 * WMW) == 0 && BM % (RPI * NW_) == 0, "tile / wave grid");
     static constexpr int WXD = WX > 0 ? WX : 1;          // (divisor of `wave % WX` where no wave moves an extra group)
     static_assert(NW_ * (32 * RSG + 640) <= NS_ * STAGE, "epilogue images must fit the ring");
     static_assert(NS_ == 3 || NS_ == 4, "ring depth");
@@ -156,10 +163,11 @@ struct EpiArgs {
 
 // the wave's 160 bias values of output columns [n0, n0 + 160) of bias row `row` (row-major [rows][N] fp32): lane l < 40 gets
 // columns 4 l .. 4 l + 3 (out of range: zeros) - ONE load, issued a k-stage or more ahead of the epilogue
+template <int WCOL = 160>
 __device__ __forceinline__ f32x4 load_bias4(const float* bias, int row, int N, int n0) {
     const GBuf bufB = make_gbuf(bias + (size_t)row * N, (uint32_t)N * 4u);
     const int ln = lane_now(), n = n0 + 4 * ln;
-    return __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < 40 && n < N) ? (uint32_t)n * 4u : kOOB));
+    return __builtin_bit_cast(f32x4, gbuf_ld8(bufB, (ln < WCOL / 4 && n < N) ? (uint32_t)n * 4u : kOOB));
 }
 
 // Epilogue of one wave tile (64 x 160 at (mw0, nw0)) through a 32 x 80-column image `stg`.  EPI 0: two column halves per
@@ -185,16 +193,19 @@ __device__ __forceinline__ f32x4 load_bias4(const float* bias, int row, int N, i
 // lies inside one frame (hw % (32 TM) == 0, M % hw == 0) and that its 160 columns hold whole groups (160 % cpg == 0, cpg even):
 // the dispatcher checks.  Two fp16 columns per v_dot2_f32_f16; lanes -> groups through the (by then idle) image; every
 // (frame, chunk, group) slot has ONE writer and the additions have a fixed order: deterministic.
-template <int EPI, int RES, int TM, int GNS = 0>
-__device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5::TN][TM], char* stg, char* bstrip, f32x4 bias4,
+// TNV = column blocks of the wave tile (5: 160 columns, two 80-column passes per 32-row block; 4: 128 columns, two 64-column passes).
+template <int EPI, int RES, int TM, int GNS = 0, int TNV = g5::TN>
+__device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[TNV][TM], char* stg, char* bstrip, f32x4 bias4,
                                               int mw0, int nw0) {
-    static_assert(!GNS || EPI == 0, "statistics of the plain epilogue only");
+    static_assert(!GNS || (EPI == 0 && TNV == 5), "statistics of the plain 160-column epilogue only");
     using namespace g5;
     constexpr int H = EPI == 1 ? 1 : 2;               // passes per 32-row block
     constexpr int NP = TM * H;                        // passes
-    constexpr int CPP = 20 / H;                       // accumulator chunks (i, q) per pass
-    constexpr int CB = 5;                             // chunks per scheduling group
-    constexpr int PITCH = RSG, SEGS = 10, RPI_OUT = 6, NIT = 6;
+    constexpr int CPP = 4 * TNV / H;                  // accumulator chunks (i, q) per pass
+    constexpr int CB = TNV == 5 ? 5 : 4;              // chunks per scheduling group
+    constexpr int HC = 16 * TNV;                      // image columns: 80 / 64 (EPI 1: outputs per row)
+    constexpr int PITCH = 2 * HC + 16, SEGS = HC / 8, RPI_OUT = 64 / SEGS, NIT = (32 + RPI_OUT - 1) / RPI_OUT;
+    static_assert(PITCH <= RSG && CPP % CB == 0, "image fits the slot laid out for 80 columns");
     const int M = a.M, N = a.N, ldc = a.ldc, ldr = a.ldr;
     const float alpha = a.alpha;
     constexpr bool has_r = EPI == 0 && RES != 0;
@@ -206,7 +217,7 @@ __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5
     const int seg = lane % SEGS, rsel = lane / SEGS;  // lanes 60..63: rsel == 6 -> out of range
     const int nout = EPI == 1 ? N / 2 : N;
     if (has_b) {
-        if (lane < 40) *reinterpret_cast<f32x4*>(bstrip + lane * 16) = bias4;
+        if (lane < 8 * TNV) *reinterpret_cast<f32x4*>(bstrip + lane * 16) = bias4;
     }
     float gsum[H][4], gsq[H][4];   // GNS: column-pair sums of the lane's 8 columns per column half, over both 32-row blocks
 #pragma unroll
@@ -216,7 +227,7 @@ __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5
     half8_t rres[NIT];     // residual rows of the pass being written (requested one pass ahead, see below)
     auto load_r = [&](int pass, half8_t* dst) {
         const int mrow = mw0 + 32 * (pass / H);
-        const int ncol = nw0 + 80 * (pass % H) + seg * 8;
+        const int ncol = nw0 + HC * (pass % H) + seg * 8;
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int r = it * RPI_OUT + rsel, m = mrow + r;
@@ -230,7 +241,7 @@ __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5
     for (int pass = 0; pass < NP; ++pass) {
         const int j = pass / H, h = pass % H;
         const int mrow = mw0 + 32 * j;
-        const int ncol = EPI == 1 ? nw0 / 2 + seg * 8 : nw0 + 80 * h + seg * 8;   // first output column of the lane's segment
+        const int ncol = EPI == 1 ? nw0 / 2 + seg * 8 : nw0 + HC * h + seg * 8;   // first output column of the lane's segment
 #pragma unroll
         for (int c0 = 0; c0 < CPP; c0 += CB) {
             f32x4 bv[CB];
@@ -261,7 +272,7 @@ __device__ __forceinline__ void tile_epilogue(const EpiArgs& a, f32x16 (&acc)[g5
                     half4_t o;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) o[e] = to_half(v[e]);
-                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + (cl - 80 * h) * 2) = o;
+                    *reinterpret_cast<half4_t*>(stg + l31 * PITCH + (cl - HC * h) * 2) = o;
                 }
             }
             MC_SCHED_FENCE();   // keeps hipcc from hoisting every chunk's arithmetic to the top (spills: each reload is a vmcnt(0))

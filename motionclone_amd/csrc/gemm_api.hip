@@ -71,6 +71,10 @@ static int gemm_one(GemmParams p, int mode, int tile, int deep, int big_cfg, int
         g_last_kernel = big_cfg == 15 ? 54 : 51;
         return gemm5_dispatch(p, mode, big_cfg - 11, rowsA, s);
     }
+    if (big_cfg == 7) {    // gemm5 with 256 x 256 tiles, FOUR waves, 128 x 128 wave tiles (round 6)
+        g_last_kernel = 57;
+        return gemm5_dispatch(p, mode, 7, rowsA, s);
+    }
     if (big_cfg == 8) {    // gemm5 with 256 x 320 tiles, FOUR waves (128 x 160 wave tiles, one wave per SIMD: round 6)
         g_last_kernel = 58;
         return gemm5_dispatch(p, mode, 6, rowsA, s);

@@ -21,7 +21,8 @@ PEAK_TFLOPS = 2500.0     # fp16 dense MFMA, MI355X_MICROARCH.md
 PEAK_HBM_GBPS = 8000.0   # spec; achievable ~6300
 
 _GEMM_KERNELS = {2: "gemm2<128x128>", 20: "gemm2<64x64>", 4: "gemm4<K=320 streaming>", 51: "gemm5<256x320>",
-                 54: "gemm5<128x320>", 56: "gemm5<256x160 x2 per CU>"}
+                 54: "gemm5<128x320>", 56: "gemm5<256x160 x2 per CU>", 57: "gemm5<256x256, 4 waves>", 58: "gemm5<256x320, 4 waves>",
+                 61: "gemm6<256x320 tile loop>", 62: "gemm6<256x320 tile loop, stream-K>"}
 _MODES = ["DENSE", "CONV_S1", "CONV_S2", "CONV_UP", "TCONV_S2"]
 
 
@@ -34,7 +35,7 @@ def _gemm_name(code, mode):
 
 def _cost(name, a):
     """-> (family, flop, bytes, shape key) of one C-ABI call with positional arguments `a`; None = not a launch"""
-    if name in ("mc_gemm_f16", "mc_gemm_splitk_f16"):
+    if name in ("mc_gemm_f16", "mc_gemm_splitk_f16", "mc_gemm_gnstats_f16"):   # (the same leading arguments)
         M, N, K, mode, flags = a[6], a[7], a[8], a[15], a[22]
         c1, ctot, Hs, Ws, Ho, Wo = a[13], a[14], a[16], a[17], a[18], a[19]
         geglu = bool(flags & 0x200)
@@ -87,6 +88,9 @@ def _cost(name, a):
     if name == "mc_groupnorm_fwd_f16":
         ctot, frames, hw = a[5], a[6], a[7]
         return ("groupnorm_fwd", 0.0, 6.0 * frames * hw * ctot, (frames * hw, ctot))
+    if name == "mc_groupnorm_fwd_partial_f16":     # statistics from the producing GEMM's epilogue: one read, one write
+        ctot, frames, hw = a[2], a[3], a[4]
+        return ("groupnorm_fwd (statistics from the producer)", 0.0, 4.0 * frames * hw * ctot, (frames * hw, ctot))
     if name == "mc_groupnorm_bwd_f16":
         ctot, frames, hw = a[5], a[6], a[7]
         return ("groupnorm_bwd", 0.0, (8.0 if a[18] else 6.0) * frames * hw * ctot, (frames * hw, ctot))
@@ -166,12 +170,29 @@ class LaunchProbe:
                 del probe.records[n0:]
             return ok
         lib.try_call = try_call
+        # ... and the ones that answer with a count (lib.call_count: mc_gemm_gnstats_f16 -> chunk height, False = nothing launched)
+        self._orig_count = lib.call_count
+
+        def call_count(name, *args):
+            if not probe.enabled:
+                return probe._orig_count(name, *args)
+            n0 = len(probe.records)
+            saved, probe._orig = probe._orig, probe._orig_count
+            try:
+                rc = call(name, *args)
+            finally:
+                probe._orig = saved
+            if rc is False:
+                del probe.records[n0:]
+            return rc
+        lib.call_count = call_count
         return self
 
     def uninstall(self):
         if self._orig is not None:
             lib.call = self._orig
             lib.try_call = self._orig_try
+            lib.call_count = self._orig_count
             self._orig = None
 
     def reset(self):

@@ -81,11 +81,20 @@ def test_the_timed_regime_row_is_built_from_the_committed_kernel_trace_and_pinne
     assert bench.family_of_traced_kernel("gemm5_kernel<0, 0, 0, 256, 160, 4, 3>") == "gemm5<256x160 x2 per CU> DENSE"
     assert bench.family_of_traced_kernel("gemm4_kernel<20, true, 1>") == "gemm4<K=320 streaming> LayerNorm + DENSE"
     assert bench.family_of_traced_kernel("gn_partial_kernel") is None
-    rt = bench.timed_roofline(roof_all, prof)
+    assert bench.family_of_traced_kernel("void mc::gemm6_kernel<1, 0, 0, 0>(mc::G6Args)") == "gemm6<256x320 tile loop> DENSE"
+    # round 6: a trace is only used if it was taken from the loaded library (source stamp), on this device, with this packing
+    stale = bench.timed_roofline(roof_all, prof)
+    assert stale["achieved"] is None and stale["frac"] is None and "stale" in stale["reason"]
+    prof.update(lib_stamp=bench.loaded_lib_stamp(), device=None, lanes=2, batch=5)      # (no GPU here: device name None on both sides)
+    other = bench.timed_roofline(roof_all, prof, 3, 1)
+    assert other["achieved"] is None and "lanes" in other["reason"]
+    line = json.loads(bench.compact_line(dict(_full_record(), roofline_timed=stale), "d.json"))
+    assert line["roofline_timed"]["achieved"] is None and "reason" in line["roofline_timed"]
+    rt = bench.timed_roofline(roof_all, prof, 2, 5)
     assert rt["kernel"] == fam and abs(rt["avg_launch_us"] - 25.0) < 1e-9
     assert abs(rt["flop_per_launch"] - 70e9) < 1 and abs(rt["achieved"] - 70e9 / 25.0 / 1e6) < 1e-6
     assert abs(rt["frac"] - rt["achieved"] / 2500.0) < 1e-12 and abs(rt["share_of_kernel_time"] - 0.5) < 1e-9 and rt["overlap"] == 1.4
-    assert bench.timed_roofline(roof_all, None) is None and bench.timed_roofline({}, prof) is None
+    assert bench.timed_roofline(roof_all, None) is None and bench.timed_roofline({}, prof, 2, 5) is None
     res = _full_record()
     res["roofline_timed"] = rt
     got = json.loads(bench.compact_line(res, "profiles/r05_bench_detail.json"))

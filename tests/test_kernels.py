@@ -84,12 +84,13 @@ def test_gemm_large_tile_geometries(backend, cfg):
     close(og, y[:, :D] * Fn.gelu(y[:, D:]), 2e-2, 1e-2, "gemm3 geglu")
 
 
-@pytest.mark.parametrize("var", [0, 4, -3])
+@pytest.mark.parametrize("var", [0, 4, -3, -4])
 def test_gemm5_ring_kernel(backend, var):
     """gemm5.hip (4-stage ring, LDS-DMA, wave-private epilogue), forced with cfg = 11 + var: dense with
     per-batch bias / residual / alpha / M and N tails / short and long K (2 .. 40 ring stages), two-source conv, fused GEGLU;
     var 4 = the 128-row tile geometry, var -3 (cfg 8) = 256 x 320 tiles on FOUR waves with 128 x 160 wave tiles (round 6: measured
-    slower than eight waves, kept as a forced configuration only)"""
+    slower than eight waves, kept as a forced configuration only), var -4 (cfg 7) = 256 x 256 tiles on four waves with 128 x 128
+    wave tiles, dense only"""
     dev = backend
     cfg = 11 + var
     # (round 6: a tile of the one-pass kernels reads ONE bias row - per-batch bias rows need rows_per_batch % tile height == 0;
@@ -107,8 +108,12 @@ def test_gemm5_ring_kernel(backend, var):
     NF, Cin, Cout, H, W = (2, 64, 72, 6, 10) if not big(dev) else (4, 128, 320, 24, 20)
     x, x2 = rnd((NF, Cin, H, W), dev, 5), rnd((NF, 64, H, W), dev, 6)
     wc = rnd((Cout, Cin + 64, 3, 3), dev, 7, 0.05)
-    o = ops.gemm(_to_cl(x), _conv_w_pack(wc), a2=_to_cl(x2), mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, cfg=cfg)
-    close(_from_cl(o, NF, H, W), Fn.conv2d(torch.cat([x, x2], 1).float(), wc.float(), padding=1), 3e-2, 5e-3, "gemm5 conv")
+    if var == -4:     # the 256 x 256 geometry is built for the dense layers only
+        with pytest.raises(RuntimeError):
+            ops.gemm(_to_cl(x), _conv_w_pack(wc), a2=_to_cl(x2), mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, cfg=cfg)
+    else:
+        o = ops.gemm(_to_cl(x), _conv_w_pack(wc), a2=_to_cl(x2), mode=ops.CONV_S1, geom=(H, W, H, W), m_out=NF * H * W, cfg=cfg)
+        close(_from_cl(o, NF, H, W), Fn.conv2d(torch.cat([x, x2], 1).float(), wc.float(), padding=1), 3e-2, 5e-3, "gemm5 conv")
     M, K, D = (300, 128, 80) if not big(dev) else (3000, 320, 640)
     a = rnd((M, K), dev, 1)
     wg = rnd((2 * D, K), dev, 8, 0.1)

@@ -15,11 +15,11 @@ for w in $WHAT; do
     bench)
       timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_stdout.log 2> gpurun_out/${TAG}_bench_stderr.log
       echo "bench rc=$?"; grep '^{' gpurun_out/${TAG}_bench_stdout.log | tail -n 1 | tee gpurun_out/${TAG}_bench_line.json | cut -c1-1500
-      cp gpurun_out/r05_bench_detail.json gpurun_out/${TAG}_bench_detail.json 2>/dev/null ;;
+      cp gpurun_out/r06_bench_detail.json gpurun_out/${TAG}_bench_detail.json 2>/dev/null ;;
     benchshort)
       timeout 600 python bench.py --steps 6 --warmup 3 --no-cpu-baseline --no-vae > gpurun_out/${TAG}_benchshort_stdout.log 2> gpurun_out/${TAG}_benchshort_stderr.log
       echo "benchshort rc=$?"; grep '^{' gpurun_out/${TAG}_benchshort_stdout.log | tail -n 1 | tee gpurun_out/${TAG}_benchshort_line.json | cut -c1-1200
-      cp gpurun_out/r05_bench_detail.json gpurun_out/${TAG}_benchshort_detail.json 2>/dev/null ;;
+      cp gpurun_out/r06_bench_detail.json gpurun_out/${TAG}_benchshort_detail.json 2>/dev/null ;;
     prof)
       ( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/${TAG}_prof" -o trace -- \
           python "$OLDPWD/bench.py" --no-cpu-baseline --no-vae --steps 3 --no-detail > "$OLDPWD/gpurun_out/${TAG}_prof_bench.log" 2>&1 )

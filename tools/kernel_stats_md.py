@@ -31,6 +31,16 @@ def bench_value(d):
         return None
 
 
+def bench_packing(d):
+    """(lanes, videos batched per lane) of the traced bench run, from its line's config"""
+    try:
+        lines = [l for l in open(os.path.join(d, "bench.json")) if l.startswith("{")]
+        c = json.loads(lines[-1])["config"]
+        return int(c.get("videos_in_flight_per_gpu", 3)), int(c.get("videos_batched_per_lane", 1))
+    except Exception:
+        return 3, 1
+
+
 def table(path, videos, top=34):
     rows = list(csv.DictReader(open(path)))
     ncalls = sum(int(r["Calls"]) for r in rows)
@@ -86,8 +96,9 @@ def durations_json(stats_path, trace_dir, videos, vpm, tag):
         device = torch.cuda.get_device_name(0) if torch.cuda.is_available() else None
     except Exception:   # noqa: BLE001
         device = None
-    return dict(lib_stamp=lib_stamp, device=device, regime="hipGraph replay, three videos in flight, no probe videos: `python bench.py --no-cpu-baseline --no-vae "
-                       "--no-probe --steps 6 --warmup 3` under rocprofv3 --kernel-trace --stats (%s)" % tag, videos_in_trace=videos, videos_per_min_under_profiler=vpm,
+    lanes, batch = bench_packing(trace_dir)
+    return dict(lib_stamp=lib_stamp, device=device, lanes=lanes, batch=batch, regime="hipGraph replay, %d lanes x %d videos, no probe videos: `%s` under rocprofv3 --kernel-trace --stats (%s)"
+                       % (lanes, batch, os.environ.get("MC_PROFILE_CMD_A", "python bench.py --no-cpu-baseline --no-vae --no-probe --steps 6 --warmup 3"), tag), videos_in_trace=videos, videos_per_min_under_profiler=vpm,
                 total_kernel_s=total, overlap=overlap, code=code, kernels=kern)
 
 
@@ -100,30 +111,34 @@ shutil.copy(pa, base + "_a.csv")
 shutil.copy(pb, base + "_b.csv")
 na, ta, ma, tab_a = table(pa, va)
 nb, tb, mb, tab_b = table(pb, vb)
+cmd_a = os.environ.get("MC_PROFILE_CMD_A", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --steps 6 --warmup 3")
+cmd_b = os.environ.get("MC_PROFILE_CMD_B", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-graphs --inflight 1 --batch 1 --steps 2")
+lanes_a, batch_a = bench_packing(a_dir)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
-`tools/gpu_profile_r05.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace: (a) warm-up +
+`tools/gpu_profile.sh` + `tools/kernel_stats_md.py`.  Launch counts per video divide by ALL videos in the trace: (a) warm-up +
 timed videos only (`--no-probe`: the trace holds the timed regime's kernels and nothing else; it is what
 `profiles/kernel_durations_timed.json` / the bench line's `roofline_timed` are made of), (b) warm-up, timed and the eager videos of
-the bench's probe pass.  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, ring stages>` (MODE 0 dense, 1
-conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU; 256, 160, 4, 3 = two workgroups per CU), `gemm4_kernel<20, GEGLU, NORM>` = K = 320 streaming
-kernel (NORM 1 = LayerNorm, 2 = GroupNorm applied to the rows in registers),
+the bench's probe pass.  Kernel names: `gemm5_kernel<MODE, EPI, VAR, BM, BN, waves, ring stages, RES, GNS>` (MODE 0 dense, 1
+conv3x3, 2 stride-2, 3 upsample+conv, 4 transposed; EPI 1 = fused GEGLU; RES 1 = residual in the epilogue; GNS 1 = the epilogue
+leaves the GroupNorm statistics of its output), `gemm6_kernel<EPI, RES, VAR, SK>` = the persistent tile loop over 256x320 tiles,
+`gemm4_kernel<20, GEGLU, NORM>` = K = 320 streaming kernel (NORM 1 = LayerNorm, 2 = GroupNorm applied to the rows in registers),
 `attn_*_ring_kernel<DT, rows/16 per wave>` = the LDS-DMA ring attention (DT 3: d = 40, 5: d = 80).
 
-## (a) `python bench.py --no-cpu-baseline --no-vae --no-probe --steps 6 --warmup 3`: hipGraph replay, three videos in flight (kernel durations are measured while kernels of the other two videos share the CUs)
+## (a) `%s`: hipGraph replay, %d lanes x %d videos batched per lane (kernel durations are measured while kernels of the other lanes share the CUs)
 
-Bench line of this run: **%s videos/min** (under the profiler); videos in the trace: 3 warm-up + 6 timed = **%d**; %d kernel launches
+Bench line of this run: **%s videos/min** (under the profiler); videos in the trace (warm-up + timed): **%d**; %d kernel launches
 = **%d per video** (%d of them this library's); total kernel time %.1f s.
 
 %s
 
-## (b) `--no-graphs --inflight 1 --steps 2`: one video at a time on the eager launch sequence (the regime of the roofline probe of bench.py)
+## (b) `%s`: one video at a time on the eager launch sequence
 
-Bench line of this run: **%s videos/min**; videos in the trace: 1 warm-up + 2 timed + 3 eager (warm-up, timed, probe) = **%d**; %d kernel launches = **%d per video**;
+Bench line of this run: **%s videos/min**; videos in the trace (warm-up, timed, eager / probe passes) = **%d**; %d kernel launches = **%d per video**;
 total kernel time %.1f s = %.2f s per video.
 
 %s
-""" % (tag, bench_value(a_dir), va, na, round(na / va), round(ma / va), ta, tab_a, bench_value(b_dir), vb, nb, round(nb / vb), tb, tb / vb, tab_b)
+""" % (tag, cmd_a, lanes_a, batch_a, bench_value(a_dir), va, na, round(na / va), round(ma / va), ta, tab_a, cmd_b, bench_value(b_dir), vb, nb, round(nb / vb), tb, tb / vb, tab_b)
 open(out_md, "w").write(md)
 json.dump(durations_json(pa, a_dir, va, bench_value(a_dir), tag), open(os.path.join(os.path.dirname(out_md), "kernel_durations_timed.json"), "w"), indent=1)
 print(out_md, "launches per video:", round(na / va), round(nb / vb))

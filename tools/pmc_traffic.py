@@ -3,7 +3,8 @@
   workload:  rocprofv3 --pmc FETCH_SIZE  --output-format csv -d OUT/FETCH_SIZE -- python tools/pmc_traffic.py run OUT
              rocprofv3 --pmc WRITE_SIZE  --output-format csv -d OUT/WRITE_SIZE -- python tools/pmc_traffic.py run OUT
   table:     python tools/pmc_traffic.py table OUT > profiles/hbm_traffic_per_shape.json   (+ a markdown table on stderr)
-  PMC_LANES=3 in the environment of `run`: the tile choice of three videos in flight (default 1 = the roofline probe's regime)
+  PMC_LANES=3 in the environment of `run`: the tile choice of three videos in flight (default 1 = the roofline probe's regime);
+  PMC_BATCH=5: V = 5 videos batched per lane (V times the rows of every launch), the packing of the round-6 bench
 
 Separate passes, counters only (MI355X_MICROARCH.md: FETCH_SIZE takes 3 of the 4 TCC slots).  Units: KiB; on gfx950 FETCH_SIZE
 reports half of a wide coalesced read, so traffic = (2 * FETCH_SIZE + WRITE_SIZE) * 1024 bytes.  The library chooses the kernel
@@ -40,7 +41,9 @@ def run(out):
     def r(*s, sc=1.0):
         return (torch.randn(*s, device=dev) * sc).half()
     order = []
+    vb = int(os.environ.get("PMC_BATCH", "1"))     # videos batched per lane: V times the rows (frames) of every launch
     for mode, M, N, K, geglu, res, geom in SHAPES:
+        M *= vb
         if mode == 0:
             x, kw = r(M, K), {}
         else:

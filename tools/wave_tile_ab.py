@@ -23,6 +23,10 @@ def r(*shape, s=1.0, seed=0):
 # name, mode, M, N, K, bias rows (0 none, 1 one, 2 per sample), residual, geglu, geom
 SHAPES = [
     ("ff1_l1 geglu", 0, 32768, 5120, 640, 1, False, True, None),
+    ("ff1_l1 plain", 0, 32768, 5120, 640, 0, False, False, None),
+    ("ff1_l2 plain", 0, 8192, 10240, 1280, 0, False, False, None),
+    ("attn_out_l2 +R", 0, 8192, 1280, 1280, 1, True, False, None),
+    ("ff2_l2 +R", 0, 8192, 1280, 5120, 1, True, False, None),
     ("ff1_l2 geglu", 0, 8192, 10240, 1280, 1, False, True, None),
     ("qkv_l2", 0, 8192, 3840, 1280, 0, False, False, None),
     ("qkv_l1", 0, 32768, 1920, 640, 0, False, False, None),
@@ -43,9 +47,12 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=8)
+    ap.add_argument("--dense-only", action="store_true")
     a = ap.parse_args()
     lib.load()
     for name, mode, M, N, K, nb, res, geglu, geom in SHAPES:
+        if a.dense_only and mode != 0:
+            continue
         if mode == 0:
             x = r(M, K, seed=1)
             kw = {}
@@ -61,8 +68,13 @@ def main():
         arms = {"8 waves (cfg 11)": dict(cfg=11), "4 waves (cfg 8)": dict(cfg=8)}
         if mode == 0:
             arms["tile loop"] = dict(tileloop=True)
+            arms["256x256, 4 waves, 128x128 wave tiles (cfg 7)"] = dict(cfg=7)
+            if not geglu and not res:
+                arms["vendor (torch.matmul)"] = None
         outs = {k: torch.empty((M, nout), dtype=torch.float16, device=dev) for k in arms}
-        fns = {k: (lambda k=k, v=v: ops.gemm(x, w, bias=bias, rows_per_batch=rpb, residual=R, geglu=geglu, out=outs[k], **kw, **v))
+        wt = w.t().contiguous()
+        fns = {k: ((lambda k=k, v=v: ops.gemm(x, w, bias=bias, rows_per_batch=rpb, residual=R, geglu=geglu, out=outs[k], **kw, **v))
+                   if v is not None else (lambda k=k: torch.matmul(x, wt, out=outs[k])))
                for k, v in arms.items()}
         for f in fns.values():
             f()
