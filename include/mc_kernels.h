@@ -91,7 +91,8 @@ int mc_gemm_gnstats_f16(const void* A, const void* A2, const void* W, void* C, c
  *     list are dealt evenly to its workgroups, tiles are cut along k where a range ends, the later pieces' fp32 sums meet the
  *     first piece's here (replaces split-K + reduce; a cut tile's sum is deterministic but not the one-chain sum).
  *   flags: 0x200 fused GEGLU; 0x2 stream-K; 0x1 A/B: drain the epilogue's stores before the next tile's first wait;
- *     bits 16-23 grid cap / 8.
+ *     0x4: tile order with the column blocks outermost (an XCD keeps sn weight panels in its L2 while all its row groups pass;
+ *     default: keeps a row group's activation panels and streams the weights past them; same results); bits 16-23 grid cap / 8.
  * Returns MC_ERR_UNSUPPORTED (-2) outside its shapes (K < 256, N % 8, two-source A, per-batch bias, M < 1793 without
  * stream-K): call mc_gemm_f16. */
 long mc_workspace_bytes_gemm_tileloop(int which);

@@ -52,10 +52,10 @@ static_assert(IMG_IN_SLOT * IMG + 4 * BSTRIP <= T::STAGE && SMEM <= 160 * 1024, 
 // local index `l` of XCD `xcd`'s tile list -> (tm, tn); false past the end.  Rows of the XCD: tm = 8 i + xcd, walked in groups
 // of sm rows, inside a group in column blocks of sn tiles, rows fastest (gemm5's super-tile order without holes).
 __device__ __forceinline__ int list_len(int xcd, int tilesM, int tilesN, int flat) {
-    return flat ? (tilesM * tilesN - xcd + 7) >> 3 : ((tilesM - xcd + 7) >> 3) * tilesN;
+    return flat == 1 ? (tilesM * tilesN - xcd + 7) >> 3 : ((tilesM - xcd + 7) >> 3) * tilesN;
 }
 __device__ __forceinline__ bool tile_of(int l, int xcd, int tilesM, int tilesN, int sm, int sn, int flat, int& tm, int& tn) {
-    if (flat) {
+    if (flat == 1) {
         const int f = 8 * l + xcd;
         if (l < 0 || f >= tilesM * tilesN) return false;
         tn = f / tilesM;
@@ -64,6 +64,18 @@ __device__ __forceinline__ bool tile_of(int l, int xcd, int tilesM, int tilesN, 
     }
     const int rows = (tilesM - xcd + 7) >> 3;
     if (l >= rows * tilesN) return false;
+    if (flat == 2) {
+        // COLUMN BLOCKS OUTERMOST (A/B, mc_gemm_tileloop_f16 flags 0x4): the sn weight panels of a column block stay in the XCD's L2
+        // while ALL of its row groups pass (W crosses the fabric once per XCD, A once per column block) - the default keeps the sm
+        // activation panels of a row group and streams W past them (A once, W once per row group)
+        const int per_blk = rows * sn;
+        const int blk = l / per_blk, idx = l - blk * per_blk;
+        const int g = idx / (sm * sn), w = idx - g * (sm * sn);
+        const int rg = min(sm, rows - g * sm);
+        tn = blk * sn + w / rg;
+        tm = (g * sm + w % rg) * 8 + xcd;
+        return true;
+    }
     const int per_group = sm * tilesN;
     const int g = l / per_group, idx = l - g * per_group;
     const int rg = min(sm, rows - g * sm);
@@ -553,13 +565,13 @@ __global__ __launch_bounds__(512, 1) void gemm6_kernel(G6Args args) {
 // mode: 0 static, 1 dynamic (ctr), 2 stream-K (ctr + slabs)
 template <int EPI, int RES, int VAR, int SK>
 static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, int mode, uint32_t* ctr, float* slabs, int max_wg,
-                   hipStream_t stream) {
+                   hipStream_t stream, int col_outer) {
     constexpr int BM = 256, BN = g5::BN;
     const int tM = (p.M + BM - 1) / BM, tN = (p.N + BN - 1) / BN, nk = p.K / g5::BKT;
     allow_big_smem(gemm6_kernel<EPI, RES, VAR, SK>, g6::SMEM);
     // super-tile of the XCD-local order: as launch5 (sm x sn ~ the 32 workgroups of an XCD, least operand rows per tile)
     const int rows_per_xcd = (tM + 7) / 8;
-    const int flat = tM < 8;
+    int flat = tM < 8;
     int sm = 1, sn = 1;
     const bool w_resident = (size_t)p.N * p.K * 2 <= (size_t)3 << 20;
     if (!w_resident && !flat) {
@@ -571,10 +583,11 @@ static int launch6(const GemmParams& p, uint32_t bA, uint32_t bW, int mode, uint
             if (best < 0 || cost < best) best = cost, sm = r, sn = c;
         }
     }
+    if (col_outer && !flat && sn < tN && tN % sn == 0) flat = 2;     // (tile_of: column blocks outermost)
     // workgroups per XCD: one per CU, no more than the longest per-XCD list (stream-K: than its stages / 2 PMIN)
     int longest = 0, shortest = 1 << 30;
     for (int x = 0; x < 8; ++x) {
-        const int len = flat ? (tM * tN - x + 7) / 8 : ((tM - x + 7) / 8) * tN;
+        const int len = flat == 1 ? (tM * tN - x + 7) / 8 : ((tM - x + 7) / 8) * tN;
         longest = std::max(longest, len);
         if (len > 0) shortest = std::min(shortest, len);
     }
@@ -617,7 +630,7 @@ int gemm6_dispatch(const GemmParams& p, int var, int mode, uint32_t* ctr, float*
     if (p.epi == 1 && ((p.N & 15) || p.R)) return MC_ERR_UNSUPPORTED;
     if (mode != 2 && (p.M + 255) / 256 < 8) return MC_ERR_UNSUPPORTED;     // every XCD owns at least one row of tiles
     if ((mode == 1 && !ctr) || (mode == 2 && (!ctr || !slabs)) || mode < 0 || mode > 2) return MC_ERR_SHAPE;
-#define MC_G6A(E, R, V, S) launch6<E, R, V, S>(p, (uint32_t)bytesA, (uint32_t)bytesW, mode, ctr, slabs, max_wg, stream)
+#define MC_G6A(E, R, V, S) launch6<E, R, V, S>(p, (uint32_t)bytesA, (uint32_t)bytesW, mode, ctr, slabs, max_wg, stream, (var & 4) != 0)
 #define MC_G6(E, R) (mode == 2 ? MC_G6A(E, R, 0, 1) : (var & 1) ? MC_G6A(E, R, 1, 0) : MC_G6A(E, R, 0, 0))
     if (p.epi == 1) return MC_G6(1, 0);
     if (p.R) return MC_G6(0, 1);

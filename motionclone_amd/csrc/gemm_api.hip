@@ -343,7 +343,7 @@ extern "C" int mc_gemm_tileloop_f16(const void* A, const void* A2, const void* W
     p.rows_per_batch = rows_per_batch; p.alpha = alpha; p.epi = epi; p.s2_pad = 1;
     p.ws = nullptr; p.splits = 1; p.dbg = 0;
     g_last_kernel = sk ? 62 : 61;
-    return gemm6_dispatch(p, flags & 1, sk ? 2 : (workspace ? 1 : 0), (uint32_t*)workspace, (float*)partials,
+    return gemm6_dispatch(p, flags & 5, sk ? 2 : (workspace ? 1 : 0), (uint32_t*)workspace, (float*)partials,
                           ((flags >> 16) & 0xFF) * 8, (hipStream_t)stream);
 }
 

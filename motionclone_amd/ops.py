@@ -124,6 +124,7 @@ _TILE_BLOCK_BYTES = 2048
 _tile_slabs = {}     # device -> zeroed int32 tensor
 _tile_blocks = {}    # (id(owner), device, stream) -> byte address
 _tile_lock = threading.Lock()
+TILELOOP_COL_OUTER = False   # tile order of the loop: column blocks outermost (mc_gemm_tileloop_f16 flags 0x4); A/B
 TILELOOP = None      # None: the measured policy of `_tileloop_wanted`; False: never; True: wherever the kernel accepts the shape
 
 
@@ -168,7 +169,7 @@ def _tileloop_wanted(M, N, K, share):
 
 
 def gemm_tileloop(a, w, *, a2=None, bias=None, residual=None, out=None, alpha=1.0, rows_per_batch=0, geglu=False,
-                  dynamic=True, strict_order=False, max_wg=0, stream_k=False):
+                  dynamic=True, strict_order=False, max_wg=0, stream_k=False, col_outer=None):
     """`gemm` (DENSE) on the persistent tile loop: out = alpha * [a | a2] . w^T + bias + residual, bit-identical to the
     256x320 kernel of mc_gemm_f16.  Returns None when the shape is outside the kernel (caller: `gemm`)."""
     _f16(a), _f16(w)
@@ -189,7 +190,9 @@ def gemm_tileloop(a, w, *, a2=None, bias=None, residual=None, out=None, alpha=1.
         if ctr is None:
             return None
         part = torch.empty(lib.workspace_bytes("gemm_tileloop", 1) // 4, dtype=torch.float32, device=a.device)
-    flags = (0x200 if geglu else 0) | (1 if strict_order else 0) | (2 if stream_k else 0) | ((max_wg // 8) << 16)
+    if col_outer is None:
+        col_outer = TILELOOP_COL_OUTER
+    flags = (0x200 if geglu else 0) | (1 if strict_order else 0) | (2 if stream_k else 0) | (4 if col_outer else 0) | ((max_wg // 8) << 16)
     ok = lib.try_call("mc_gemm_tileloop_f16", _p(a), _p(a2), _p(w), _p(out), _p(residual), _p(bias), M, N, K, _ld(a),
                       _ld(a2), _ld(out), _ld(residual), c1, rows_per_batch, float(alpha), flags, ctr,
                       _TILE_BLOCK_BYTES if ctr else 0, _p(part), part.numel() * 4 if part is not None else 0, st)

@@ -1,5 +1,8 @@
 cd "${GRAFT_REPO_ROOT:-.}"; export TMPDIR=/tmp; mkdir -p gpurun_out
-timeout 600 python -m pytest tests/test_operand_fuzz.py -m gpu -q -p no:cacheprovider 2>&1 | grep -E "^E  .*(Error|assert)|^FAILED|passed|failed" | cut -c1-300 > gpurun_out/r06f_fuzz.log; tail -n 8 gpurun_out/r06f_fuzz.log
-timeout 900 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/r06g_bench_stdout.log 2> gpurun_out/r06g_bench_stderr.log
-echo "bench rc=$?"; grep '^{' gpurun_out/r06g_bench_stdout.log | tail -n 1 | tee gpurun_out/r06g_bench_line.json | cut -c1-2500; tail -n 5 gpurun_out/r06g_bench_stderr.log
-cp profiles/r06_bench_detail.json gpurun_out/r06g_bench_detail.json 2>/dev/null
+d=gpurun_out/prof_try_2x5_nographs; mkdir -p $d
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --steps 10 --warmup 10 > $d/bench.json 2> $d/bench.err; echo "trace 2x5 no-graphs rc=$?"
+find $d -name "*kernel_trace.csv" -delete
+grep '^{' $d/bench.json | cut -c1-200; tail -n 3 $d/bench.err | cut -c1-200
+d=gpurun_out/prof_try_2x3_b; mkdir -p $d
+HSA_ENABLE_DEBUG=0 timeout 900 rocprofv3 --kernel-trace --output-format csv -d $d -- python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --steps 6 --warmup 6 > $d/bench.json 2> $d/bench.err; echo "trace 2x3 graphs, no --stats rc=$?"
+find $d -name "*kernel_trace.csv" -size +200M -delete; ls -la $d/*/ 2>/dev/null | head

@@ -97,7 +97,7 @@ def durations_json(stats_path, trace_dir, videos, vpm, tag):
     except Exception:   # noqa: BLE001
         device = None
     lanes, batch = bench_packing(trace_dir)
-    return dict(lib_stamp=lib_stamp, device=device, lanes=lanes, batch=batch, regime="hipGraph replay, %d lanes x %d videos, no probe videos: `%s` under rocprofv3 --kernel-trace --stats (%s)"
+    return dict(lib_stamp=lib_stamp, device=device, lanes=lanes, batch=batch, regime="%d lanes x %d videos in flight, no probe videos: `%s` under rocprofv3 --kernel-trace --stats (%s)"
                        % (lanes, batch, os.environ.get("MC_PROFILE_CMD_A", "python bench.py --no-cpu-baseline --no-vae --no-probe --steps 6 --warmup 3"), tag), videos_in_trace=videos, videos_per_min_under_profiler=vpm,
                 total_kernel_s=total, overlap=overlap, code=code, kernels=kern)
 
@@ -125,7 +125,7 @@ leaves the GroupNorm statistics of its output), `gemm6_kernel<EPI, RES, VAR, SK>
 `gemm4_kernel<20, GEGLU, NORM>` = K = 320 streaming kernel (NORM 1 = LayerNorm, 2 = GroupNorm applied to the rows in registers),
 `attn_*_ring_kernel<DT, rows/16 per wave>` = the LDS-DMA ring attention (DT 3: d = 40, 5: d = 80).
 
-## (a) `%s`: hipGraph replay, %d lanes x %d videos batched per lane (kernel durations are measured while kernels of the other lanes share the CUs)
+## (a) `%s`: %d lanes x %d videos batched per lane (kernel durations are measured while kernels of the other lane share the CUs)
 
 Bench line of this run: **%s videos/min** (under the profiler); videos in the trace (warm-up + timed): **%d**; %d kernel launches
 = **%d per video** (%d of them this library's); total kernel time %.1f s.

@@ -37,6 +37,7 @@ def run(out):
     # the tile choice depends on how many launch sequences the caller keeps in flight (ops.set_gemm_share): PMC_LANES = 1 is the
     # regime of bench.py's roofline probe, 3 the timed region's
     ops.set_gemm_share(int(os.environ.get("PMC_LANES", "1")))
+    ops.TILELOOP_COL_OUTER = os.environ.get("PMC_COL_OUTER", "0") == "1"      # A/B: tile order of the persistent loop
 
     def r(*s, sc=1.0):
         return (torch.randn(*s, device=dev) * sc).half()
@@ -80,7 +81,7 @@ def table(out):
     print("| kernel | mode M N K | HBM MB per launch | algorithmic MB | ratio |\n|---|---|---|---|---|", file=sys.stderr)
     for (k, sh), ts in agg.items():
         mode, M, N, K, geglu, resid = sh
-        g = [g for (m_, M_, N_, K_, gg, rr, g) in SHAPES if (m_, M_, N_, K_, gg, rr) == sh][0]
+        g = [g for (m_, M_, N_, K_, gg, rr, g) in SHAPES if (m_, N_, K_, gg, rr) == (mode, N, K, geglu, resid) and M % M_ == 0][0]
         rows_in = M if mode == 0 else (M // (g[2] * g[3])) * g[0] * g[1]
         k_in = K if mode == 0 else K // 9
         alg = 2.0 * (rows_in * k_in + N * K + M * (N // 2 if geglu else N) * (2 if resid else 1))

@@ -48,11 +48,13 @@ def main():
     ap.add_argument("--rounds", type=int, default=5)
     ap.add_argument("--iters", type=int, default=8)
     ap.add_argument("--dense-only", action="store_true")
+    ap.add_argument("--scale-m", type=int, default=1, help="V videos batched per lane: V times the rows of every shape")
     a = ap.parse_args()
     lib.load()
     for name, mode, M, N, K, nb, res, geglu, geom in SHAPES:
         if a.dense_only and mode != 0:
             continue
+        M *= a.scale_m
         if mode == 0:
             x = r(M, K, seed=1)
             kw = {}
@@ -68,12 +70,15 @@ def main():
         arms = {"8 waves (cfg 11)": dict(cfg=11), "4 waves (cfg 8)": dict(cfg=8)}
         if mode == 0:
             arms["tile loop"] = dict(tileloop=True)
+            arms["tile loop, column blocks outermost"] = "col"
             arms["256x256, 4 waves, 128x128 wave tiles (cfg 7)"] = dict(cfg=7)
             if not geglu and not res:
                 arms["vendor (torch.matmul)"] = None
         outs = {k: torch.empty((M, nout), dtype=torch.float16, device=dev) for k in arms}
         wt = w.t().contiguous()
-        fns = {k: ((lambda k=k, v=v: ops.gemm(x, w, bias=bias, rows_per_batch=rpb, residual=R, geglu=geglu, out=outs[k], **kw, **v))
+        fns = {k: ((lambda k=k: ops.gemm_tileloop(x, w, bias=bias, rows_per_batch=rpb, residual=R, geglu=geglu, out=outs[k], col_outer=True))
+                   if v == "col" else
+                   (lambda k=k, v=v: ops.gemm(x, w, bias=bias, rows_per_batch=rpb, residual=R, geglu=geglu, out=outs[k], **kw, **v))
                    if v is not None else (lambda k=k: torch.matmul(x, wt, out=outs[k])))
                for k, v in arms.items()}
         for f in fns.values():
