@@ -355,6 +355,8 @@ def compact_line(res, detail_path, limit=4000):
     if res.get("eager"):
         line["eager_one_video_at_a_time_videos_per_min"] = res["eager"]["videos_per_min"]
         line["identical_to_eager_path"] = res["eager"]["identical_to_graph_path"]
+    if res.get("three_lanes_x_one_video") and "videos_per_min" in res["three_lanes_x_one_video"]:
+        line["three_lanes_x_one_video_videos_per_min"] = res["three_lanes_x_one_video"]["videos_per_min"]
     if res.get("hbm_footprint"):
         line["peak_reserved_gib"] = res["hbm_footprint"]["peak_reserved_gib"]
     if "warmup_seconds" in res:
@@ -632,8 +634,33 @@ def main():
         probe.enabled = False
         ops.set_gemm_share(args.gemm_lanes or NF)
         eager_info = dict(videos_per_min=60.0 / te, sec_per_video=te, identical_to_graph_path=bool(torch.equal(out_e, out)),
-                          note="same launch sequence without hipGraphs, one video; not part of `value`")
+                          note="same launch sequence without hipGraphs, one lane (its --batch videos); not part of `value`")
         del sme
+    # Round 6: next to the packed `value`, the regime of rounds 3 - 5 - THREE lanes x ONE video, which is also what the launcher
+    # (motionclone_amd.launch --lanes 3) gives the unmodified entry scripts, whose calls carry one example each.  Six videos
+    # after their own warm-up round, outside the timed region.
+    lanes_only = None
+    if rank == 0 and world == 1 and not args.no_probe and use_graphs and VB > 1 and not args.sparsectrl:
+        try:
+            ops.set_gemm_share(3)
+            sm3 = [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
+                                      num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE) for _ in range(3)]
+            for sm in sm3:
+                sm.enable_graphs()
+            st3 = [torch.cuda.Stream(device=dev) for _ in range(3)]
+            sample_interleaved(sm3, all_inputs[:3], st3, add_noise_step=400)       # captures
+            torch.cuda.synchronize()
+            t3 = time.perf_counter()
+            for _ in range(2):
+                sample_interleaved(sm3, all_inputs[:3], st3, add_noise_step=400)
+            torch.cuda.synchronize()
+            lanes_only = dict(videos_per_min=6 * 60.0 / (time.perf_counter() - t3), lanes=3, videos_per_lane=1, videos=6,
+                              note="round 5's regime (one video per launch sequence): what `motionclone_amd.launch --lanes 3` runs "
+                                   "for the unmodified entry scripts; `value` batches %d videos per lane through the sampler API" % VB)
+            del sm3
+        except Exception as e:   # noqa: BLE001  (an extra: never costs the record)
+            lanes_only = {"error": "%s: %s" % (type(e).__name__, e)}
+        ops.set_gemm_share(args.gemm_lanes or NF)
     graph_info = dict(enabled=use_graphs, graphs=sum(len(sm._graphs) for sm in smps) if use_graphs else 0,
                       note="one graph per DDIM step, captured during warm-up; latents / text / representation refreshed by "
                            "device copies into static buffers before each replay; extraction eager")
@@ -730,6 +757,7 @@ def main():
             "warmup_videos_run": warm_videos, "warmup_seconds": warm_seconds,
             "graphs": graph_info,
             "eager": eager_info,
+            "three_lanes_x_one_video": lanes_only,
         }
         if world == 1 and not args.no_cpu_baseline:
             del eng, smp, smps

@@ -196,3 +196,20 @@ def test_probe_prices_the_fused_norm_gemm_by_its_own_arguments():
     fam, fl, nb, shape = probe._cost("mc_norm_gemm_f16", args[:9] + (2,) + args[10:18] + (0x200, 0))
     assert fam.startswith("gemm4<K=320 streaming> GroupNorm") and nb == 2.0 * (2 * M * K + N * K + M * N // 2) and shape[-1] is True
     assert probe._gemm_name(56, 0) == "gemm5<256x160 x2 per CU> DENSE" and probe._gemm_name(151, 1).endswith("CONV_S1 split-K + reduce")
+
+
+def test_automatic_packing_divides_the_timed_videos(bench):
+    """round 6: without --inflight / --batch the bench packs config 2 as two lanes x up to five batched videos, and only where
+    lanes x batch divides --steps (every round a full one: EXACTLY --steps videos are timed); other shapes and SparseCtrl keep
+    one video per lane"""
+    assert bench.auto_packing(20, 16, 512, False) == (2, 5)        # the driver's command
+    assert bench.auto_packing(6, 16, 512, False) == (2, 3)         # the no-flag default
+    assert bench.auto_packing(8, 16, 512, False) == (2, 4)
+    assert bench.auto_packing(7, 16, 512, False) == (3, 1)
+    assert bench.auto_packing(4, 16, 512, False) == (2, 2)
+    assert bench.auto_packing(6, 16, 512, True) == (3, 1)
+    assert bench.auto_packing(2, 32, 768, False) == (2, 1)
+    assert bench.auto_packing(16, 16, 256, False) == (3, 1)
+    for k in range(1, 41):
+        nf, vb = bench.auto_packing(k, 16, 512, False)
+        assert vb == 1 or k % (nf * vb) == 0
