@@ -415,7 +415,7 @@ def write_detail(res):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=6, help="videos timed per GPU")
+    ap.add_argument("--steps", type=int, default=10, help="videos timed per GPU (10 = one round of the automatic packing, 2 lanes x 5)")
     ap.add_argument("--warmup", type=int, default=1, help="untimed warm-up videos per GPU")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=512)
@@ -642,6 +642,7 @@ def main():
     lanes_only = None
     if rank == 0 and world == 1 and not args.no_probe and use_graphs and VB > 1 and not args.sparsectrl:
         try:
+            torch.cuda.empty_cache()       # what the eager / probe passes left cached (~60 GiB at 5 batched videos)
             ops.set_gemm_share(3)
             sm3 = [MotionCloneSampler(eng, cfg_scale=7.5, motion_guidance_weight=2000.0, warm_up_steps=10, cool_up_steps=10,
                                       num_inference_steps=N_STEPS, guidance_steps=G_STEPS, guidance_scale=G_SCALE) for _ in range(3)]
