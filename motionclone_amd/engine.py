@@ -450,7 +450,7 @@ class UNet3DEngine:
         # cross-attention to the text (K/V are frame-invariant: computed once per batch element)
         q2, ls2 = self._ln_gemm(h1, b + "norm2.weight", b + "norm2.bias", w.lin(b + "attn2.to_q.weight"), tape)
         if shared_geo is not None:     # the junction: both halves continue from the same rows
-            h1B, q2B, xB = torch.cat([h1, h1], 0), torch.cat([q2, q2], 0), torch.cat([x, x], 0)
+            h1B, q2B, xB = ops.dup_rows(h1), ops.dup_rows(q2), ops.dup_rows(x)
         else:
             h1B, q2B, xB = h1, q2, x
         kv = ops.gemm(text2d, w.cat_lin([b + "attn2.to_k.weight", b + "attn2.to_v.weight"]))
@@ -672,7 +672,7 @@ class UNet3DEngine:
         if geoA is not None:
             # the skip copy of conv_in's output serves both halves of the batch; gradients (all of the differentiated,
             # i.e. shared, rows) pass straight through to the one copy
-            xs = torch.cat([x, x], 0)
+            xs = ops.dup_rows(x)
             if tape is not None:
                 tape.add(lambda xs=xs, x0=x: (lambda g: tape.give(x0, g) if g is not None else None)(tape.take(xs)))
             skips = [(xs, geo)]

@@ -35,6 +35,19 @@ elif what == "widen":
         for _ in range(2):
             torch.matmul(x, w.t(), out=o)
     print("order: for (M, N, K) in %s: 2 x gemm5 <256 x 320>, 2 x torch.matmul" % (shapes,))
+elif what == "widen6":
+    # round 6: the same three layers - gemm5 one-pass (cfg 11), the persistent tile loop (gemm6, the library's choice), the 256 x 256
+    # four-wave geometry (cfg 7) and torch.matmul (hipBLASLt), two launches each
+    shapes = [(32768, 5120, 640), (8192, 10240, 1280), (8192, 3840, 1280)]
+    ops_ = [(r(M, K), r(N, K, sc=0.02), torch.empty(M, N, device=dev, dtype=torch.float16)) for M, N, K in shapes]
+    torch.cuda.synchronize()
+    for x, w, o in ops_:
+        for kw in (dict(cfg=11), dict(tileloop=True), dict(cfg=7)):
+            for _ in range(2):
+                ops.gemm(x, w, out=o, **kw)
+        for _ in range(2):
+            torch.matmul(x, w.t(), out=o)
+    print("order: for (M, N, K) in %s: 2 x gemm5 <256 x 320>, 2 x gemm6 tile loop, 2 x gemm5 <256 x 256, 4 waves>, 2 x torch.matmul" % (shapes,))
 elif what == "gemm":
     F = 32
     x1, wq1, wo1, r1 = r(32768, 640), r(1920, 640, sc=0.02), r(640, 640, sc=0.02), r(32768, 640)
