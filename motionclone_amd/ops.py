@@ -229,6 +229,7 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
     if out is None:
         out = empty((M, n_out), a)
     assert out.shape[0] == M and out.shape[1] == n_out
+    _untag(out)
     share = gemm_share()
     if tileloop is None:
         tileloop = TILELOOP
@@ -270,6 +271,12 @@ def gemm(a, w, *, a2=None, bias=None, residual=None, out=None, mode=DENSE, geom=
              _ld(out), _ld(residual), c1, ctot, mode, Hs, Ws, Ho, Wo, rows_per_batch, float(alpha), flags,
              _stream(a))
     return (out, None) if gn_hw else out
+
+
+def _untag(out):
+    """a tensor that is written again no longer holds what its GroupNorm statistics were taken from"""
+    if out is not None and hasattr(out, "_mc_gnp"):
+        del out._mc_gnp
 
 
 def gnp_of(x, hw):
@@ -554,6 +561,7 @@ def add(a, b=None, out=None, sa=1.0, sb=1.0):
     M, C = a.shape
     if out is None:
         out = empty((M, C), a)
+    _untag(out)
     lib.call("mc_add_f16", _p(a), _ld(a), _p(b), _ld(b), _p(out), _ld(out), M, C, float(sa), float(sb), _stream(a))
     return out
 
