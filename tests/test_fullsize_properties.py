@@ -140,3 +140,41 @@ def test_two_videos_in_flight_are_bit_identical_to_one_at_a_time(full):
             for k in range(2):
                 assert torch.equal(out[k], seq[k]), "lane %d differs (graphs=%s, pass %d): max |d| %.3g" % (
                     k, graphs, attempt, (out[k].float() - seq[k].float()).abs().max().item())
+
+
+def test_five_videos_batched_in_one_launch_sequence_are_their_separate_steps(full):
+    """round 6: the packing bench.py times - FIVE config-2 videos through ONE launch sequence ([5, ...] latents, text
+    [u_1 .. u_5 | c_1 .. c_5], five representations; the 16 x 16 / 8 x 8 levels then run on one-pass 256-row tiles, the GroupNorm
+    statistics come from the convs' epilogues at 5 x the frames, descriptors approach 2 GiB): every video's guided step (latents,
+    guidance gradient, its share of the loss) and plain step agree with the step it takes ALONE up to the tile choice's fp32
+    summation order (2e-3 latents / 2e-2 gradient, the bounds of the tiny simulator case)."""
+    eng, smp, lat, text, vid, noise = full
+    dev = lat.device
+    V = 5
+    vids = []
+    for v in range(V):
+        g = torch.Generator(device=dev).manual_seed(500 + v)
+        vids.append((torch.randn(lat.shape, generator=g, device=dev, dtype=torch.float16),
+                     torch.randn(text.shape, generator=g, device=dev).half(),
+                     (0.18215 * torch.randn(vid.shape, generator=g, device=dev)).half(),
+                     torch.randn(noise.shape, generator=g, device=dev, dtype=torch.float16)))
+    reps = [smp.extract(vd, nz, tx[0:1], add_noise_step=400) for (_, tx, vd, nz) in vids]
+    rep_devs = [eng.prepare_representation(r) for r in reps]
+    rep_cat = eng.prepare_representation(reps)
+    latV = torch.cat([v[0] for v in vids], 0)
+    textV = torch.cat([v[1][0:1] for v in vids] + [v[1][1:2] for v in vids], 0)
+    for i in (0, smp.G):
+        auxV = {}
+        nxtV = smp.step(latV, i, textV, rep_cat, aux=auxV).clone()
+        assert nxtV.shape == latV.shape and torch.isfinite(nxtV.float()).all()
+        loss_sum = 0.0
+        for v, (l1, t1, _, _) in enumerate(vids):
+            aux1 = {}
+            nxt1 = smp.step(l1, i, t1, rep_devs[v], aux=aux1)
+            assert rel(nxtV[v:v + 1], nxt1) < 2e-3, (i, v, rel(nxtV[v:v + 1], nxt1))
+            if i < smp.G:
+                assert rel(auxV["grad"][v:v + 1], aux1["grad"]) < 2e-2, (v, rel(auxV["grad"][v:v + 1], aux1["grad"]))
+                loss_sum += float(aux1["loss"])
+        if i < smp.G:
+            assert abs(float(auxV["loss"]) - loss_sum) < 2e-3 * abs(loss_sum), (float(auxV["loss"]), loss_sum)
+    torch.cuda.empty_cache()
