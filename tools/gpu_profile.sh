@@ -8,7 +8,7 @@ cd "$GRAFT_REPO_ROOT" 2>/dev/null || true
 export TMPDIR=/tmp
 T=${1:-r06}
 mkdir -p gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b
-if [ "$2" != "skip-pytest" ]; then
+if [ "$2" != "skip-pytest" ] && [ "$2" != "traces-only" ]; then
   timeout 1700 python -m pytest tests -m gpu -q -p no:cacheprovider --durations=8 > gpurun_out/${T}_pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -n 4 gpurun_out/${T}_pytest_gpu.log
   timeout 300 python __graft_entry__.py --smoke 2>&1 | tail -n 2
 fi
@@ -17,17 +17,19 @@ fi
 # suite are clean).  The eager run issues the same kernels in the same order on the same two streams with the same packing; only the
 # launch mechanism differs (32.1 instead of 38 videos/min under the profiler: host launch gaps, which a per-kernel duration does not see)
 export MC_PROFILE_CMD_A="python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --steps 10 --warmup 10"
-export MC_PROFILE_CMD_B="python bench.py --no-cpu-baseline --no-vae --no-detail --no-graphs --inflight 1 --batch 1 --steps 2"
+# (b) = the regime of the bench's roofline probe: ONE lane's job (five videos batched into one launch sequence) alone on the eager launches
+export MC_PROFILE_CMD_B="python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --inflight 1 --batch 5 --steps 5 --warmup 5"
 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_a -- $MC_PROFILE_CMD_A > gpurun_out/prof_${T}_a/bench.json 2> gpurun_out/prof_${T}_a/bench.err
 echo "trace a rc=$?"
 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_b -- $MC_PROFILE_CMD_B > gpurun_out/prof_${T}_b/bench.json 2> gpurun_out/prof_${T}_b/bench.err
 echo "trace b rc=$?"
-# videos in the traces: (a) 10 warm-up + 10 timed; (b) 1 warm-up + 2 timed + 3 eager (warm-up, timed, probe)
-python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/${T}_kernel_stats.md "round-6" 20 6 || echo "kernel_stats_md failed"
+# videos in the traces: (a) 10 warm-up + 10 timed; (b) 5 warm-up + 5 timed
+python tools/kernel_stats_md.py gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b gpurun_out/${T}_kernel_stats.md "round-6" 20 10 || echo "kernel_stats_md failed"
 find gpurun_out/prof_${T}_a gpurun_out/prof_${T}_b -name "*kernel_trace.csv" -delete
 python -c "
 import json; d=json.load(open('gpurun_out/kernel_durations_timed.json')); print('timed durations:', len(d['kernels']), 'kernels, total', round(d['total_kernel_s'],2), 's, overlap', d['overlap'], 'lanes x batch', d['lanes'], d['batch'], 'stamp', str(d['lib_stamp'])[:12], d['device'])"
 cp gpurun_out/kernel_durations_timed.json profiles/kernel_durations_timed.json    # what the bench line's roofline_timed reads (same box, same code)
+if [ "$2" = "traces-only" ]; then exit 0; fi
 timeout 1000 python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/${T}_bench_final.log 2> gpurun_out/${T}_bench_final.err
 echo "driver-like bench rc=$?"; grep '^{' gpurun_out/${T}_bench_final.log | tail -n 1 > gpurun_out/${T}_bench_final_line.json; cut -c1-2200 gpurun_out/${T}_bench_final_line.json; echo
 cp gpurun_out/r06_bench_detail.json gpurun_out/${T}_bench_final_detail.json

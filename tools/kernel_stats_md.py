@@ -112,7 +112,7 @@ shutil.copy(pb, base + "_b.csv")
 na, ta, ma, tab_a = table(pa, va)
 nb, tb, mb, tab_b = table(pb, vb)
 cmd_a = os.environ.get("MC_PROFILE_CMD_A", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --steps 6 --warmup 3")
-cmd_b = os.environ.get("MC_PROFILE_CMD_B", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-graphs --inflight 1 --batch 1 --steps 2")
+cmd_b = os.environ.get("MC_PROFILE_CMD_B", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --inflight 1 --batch 5 --steps 5 --warmup 5")
 lanes_a, batch_a = bench_packing(a_dir)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
@@ -132,9 +132,9 @@ Bench line of this run: **%s videos/min** (under the profiler); videos in the tr
 
 %s
 
-## (b) `%s`: one video at a time on the eager launch sequence
+## (b) `%s`: ONE lane's job alone on the eager launch sequence (the regime of the roofline probe of bench.py: `roofline.avg_launch_us` is measured there with HIP events)
 
-Bench line of this run: **%s videos/min**; videos in the trace (warm-up, timed, eager / probe passes) = **%d**; %d kernel launches = **%d per video**;
+Bench line of this run: **%s videos/min**; videos in the trace (warm-up + timed) = **%d**; %d kernel launches = **%d per video**;
 total kernel time %.1f s = %.2f s per video.
 
 %s
