@@ -18,7 +18,7 @@ fi
 # launch mechanism differs (32.1 instead of 38 videos/min under the profiler: host launch gaps, which a per-kernel duration does not see)
 export MC_PROFILE_CMD_A="python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --steps 10 --warmup 10"
 # (b) = the regime of the bench's roofline probe: ONE lane's job (five videos batched into one launch sequence) alone on the eager launches
-export MC_PROFILE_CMD_B="python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --inflight 1 --batch 5 --steps 5 --warmup 5"
+export MC_PROFILE_CMD_B="python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --inflight 1 --batch 5 --gemm-lanes 2 --steps 5 --warmup 5"
 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_a -- $MC_PROFILE_CMD_A > gpurun_out/prof_${T}_a/bench.json 2> gpurun_out/prof_${T}_a/bench.err
 echo "trace a rc=$?"
 timeout 700 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${T}_b -- $MC_PROFILE_CMD_B > gpurun_out/prof_${T}_b/bench.json 2> gpurun_out/prof_${T}_b/bench.err

@@ -112,7 +112,7 @@ shutil.copy(pb, base + "_b.csv")
 na, ta, ma, tab_a = table(pa, va)
 nb, tb, mb, tab_b = table(pb, vb)
 cmd_a = os.environ.get("MC_PROFILE_CMD_A", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --steps 6 --warmup 3")
-cmd_b = os.environ.get("MC_PROFILE_CMD_B", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --inflight 1 --batch 5 --steps 5 --warmup 5")
+cmd_b = os.environ.get("MC_PROFILE_CMD_B", "python bench.py --no-cpu-baseline --no-vae --no-detail --no-probe --no-graphs --inflight 1 --batch 5 --gemm-lanes 2 --steps 5 --warmup 5")
 lanes_a, batch_a = bench_packing(a_dir)
 md = """# rocprofv3 --kernel-trace --stats of the final %s code (1x MI355X)
 
